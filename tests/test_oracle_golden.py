@@ -1,0 +1,184 @@
+"""Pin the CPU oracle (oracle/reseg_ref.py) against outputs of the upstream reference itself.
+
+The fixtures under tests/golden/ were produced by oracle/gen_golden.py, which runs the
+reference network (/root/reference/code/lib/archs/reseg.py) on inputs re-synthesised here from
+the same seeds.  No GPU, no reference tree needed at test time.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as G
+import reseg_ref as R
+
+
+def assert_index_map(ref_bits, mine_bits, margin, scale, what, rel=1e-5):
+    """Index maps are bit-exact EXCEPT at positions whose deciding margin is inside fp32 rounding
+    of the logits (|l1-l0| < rel*scale): there the reference's own choice is rounding noise."""
+    bad = (ref_bits != mine_bits)
+    hard = bad & (margin >= rel * scale)
+    assert not hard.any(), (what, int(hard.sum()))
+    assert bad.sum() <= max(1, int(1e-4 * bad.size)), (what, int(bad.sum()))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def inputs_for(z, dtype=torch.float32):
+    size, batch, seed = (int(v) for v in z["meta/size_batch_seed"])
+    x, sem, ins, n = R.synth_batch(batch, size, size, seed=seed)
+    return x.to(dtype), sem, ins, n
+
+
+def sd_as(dtype):
+    sd = R.synth_state_dict(23, True)
+    return {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("case", ["infer_32", "infer_256"])
+def test_inference_matches_reference(golden_dir, case):
+    z = load(golden_dir, case)
+    x, _, _, _ = inputs_for(z)
+    ctx = R.Ctx(capture=True)
+    with torch.no_grad():
+        out = R.reseg_forward(sd_as(torch.float32), x, ctx=ctx)
+    for nm in ("x_dec", "x1", "x2", "x3", "x4", "x5"):
+        err, cs = G.compare(z, "unet." + nm, ctx.taps["unet." + nm].numpy())
+        assert err < 1e-4 and cs < 1e-4, (nm, err, cs)
+    err, cs = G.compare(z, "sem_out", out["sem_out"].numpy())
+    assert err < 1e-4, err
+    so = out["sem_out"]
+    margin = (so[:, 1] - so[:, 0]).abs().numpy()
+    scale = float(so.abs().max())
+    assert_index_map(G.unpack_bits(z, "sem_argmax")[:, 0], out["sem_argmax"].numpy()[:, 0] != 0,
+                     margin, scale, "sem_argmax")
+    prob = torch.softmax(so, 1)[:, 1] > 0.5
+    assert_index_map(G.unpack_bits(z, "sem_prob_gt_half"), prob.numpy(), margin, scale, "prob>0.5")
+
+
+def run_with_gt(z, dtype, training):
+    x, sem, ins, n = inputs_for(z, dtype)
+    sel = [[int(v) for v in row if v >= 0] for row in z["inject/selected_idx"]]
+    P = sd_as(dtype)
+    if training:
+        P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+             for k, v in P.items()}
+    ctx = R.Ctx(bn_train=training, training=training, capture=True, drop_rate=0.0)
+    st = R.HeadState()
+    pick = (lambda a: torch.topk(a, 3, dim=1).indices[:, 2])
+    if training:
+        out = R.reseg_forward(P, x, sem, ins, n, ctx=ctx, state=st, selected_idx=sel, sample_fn=pick)
+    else:
+        with torch.no_grad():
+            out = R.reseg_forward(P, x, sem, ins, n, ctx=ctx, state=st, selected_idx=sel)
+    return P, ctx, st, out, (x, sem, ins, n)
+
+
+def check_taps(z, ctx, out, tol):
+    for nm in ("unet.x_dec", "unet.x1", "unet.x5", "x_enc", "s_sp.out", "attend.pro_split",
+               "attend.pro_merge"):
+        err, cs = G.compare(z, nm, ctx.taps[nm].detach().numpy())
+        assert err < tol, (nm, err)
+    n_it = len(out["trace"])
+    assert n_it == z["inject/s_t"].shape[0]
+    for it in range(n_it):
+        assert out["trace"][it]["s_t"] == [int(v) for v in z["inject/s_t"][it]]      # int: exact
+        for lvl in range(5):
+            pre = "it%d.L%d" % (it, lvl)
+            err, _ = G.compare(z, pre + ".x", ctx.taps[pre + ".x"].detach().numpy())
+            assert err < tol, (pre, err)
+            pred = ctx.taps[pre + ".pred"].detach()
+            err, _ = G.compare(z, pre + ".pred", pred.numpy())
+            assert err < tol, (pre, err)
+            tgt = out["trace"][it]["targets"][lvl].numpy() != 0
+            assert np.array_equal(G.unpack_bits(z, pre + ".target"), tgt)             # int: exact
+            mine = (pred[:, 1] > pred[:, 0]).numpy()
+            ref = G.unpack_bits(z, pre + ".mask_pred")
+            margin = (pred[:, 1] - pred[:, 0]).abs().numpy()
+            assert_index_map(ref, mine, margin, max(1.0, float(pred.abs().max())), pre, rel=1e-4)
+
+
+def test_eval_with_gt_matches_reference(golden_dir):
+    z = load(golden_dir, "evalgt_64")
+    P, ctx, st, out, _ = run_with_gt(z, torch.float32, training=False)
+    check_taps(z, ctx, out, 2e-4)
+    for k in ("ins_cost", "criterion", "ins_ce_loss", "ins_dice_loss"):
+        ref = float(z["scalars/" + k][0])
+        assert abs(float(out[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(out[k]), ref)
+
+
+@pytest.mark.parametrize("case,dtype,tol,gtol", [
+    ("train_64_f64", torch.float64, 1e-6, 1e-6),      # fixture stores float32 samples of an f64 run
+    ("train_64", torch.float32, 2e-4, None),
+])
+def test_train_step_matches_reference(golden_dir, case, dtype, tol, gtol):
+    z = load(golden_dir, case)
+    P, ctx, st, out, (x, sem, ins, n) = run_with_gt(z, dtype, training=True)
+    check_taps(z, ctx, out, tol)
+    assert bool(z["scalars/ins_cost_isnan"][0]) and bool(torch.isnan(out["ins_cost"]))
+    for k in ("criterion", "ins_ce_loss", "ins_dice_loss"):
+        ref = float(z["scalars/" + k][0])
+        assert abs(float(out[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), k
+    assert abs(st.baseline - float(z["scalars/baseline"][0])) < 1e-6
+    ce, dice = R.sem_losses(out["sem_out"], sem)
+    assert abs(float(ce) - float(z["scalars/sem_ce"][0])) < 1e-5
+    assert abs(float(dice) - float(z["scalars/sem_dice"][0])) < 1e-5
+    (out["ins_cost_finite"] + ce + dice).backward()
+    # the 9 parameters that never receive a gradient
+    none_ref = sorted(k[len("grad_none/"):] for k in z.files if k.startswith("grad_none/"))
+    assert len(none_ref) == 9
+    for k in none_ref:
+        assert P[k].grad is None or float(P[k].grad.abs().max()) == 0.0
+    names = sorted(set(k.split("/")[1] for k in z.files if k.startswith("grad/")))
+    gmax = max(float(np.sqrt(z["grad/%s/sums" % k][2])) for k in names)
+    worst = 0.0
+    for k in names:
+        shape = tuple(int(v) for v in z["grad/%s/shape" % k])
+        g = P[k].grad.numpy().reshape(shape)
+        err, _ = G.compare(z, "grad/" + k, g, 512)
+        l2 = float(np.sqrt(z["grad/%s/sums" % k][2]))
+        if l2 > 1e-6 * gmax:                      # skip gradients that are zero by construction
+            worst = max(worst, err)
+            if gtol is not None:
+                assert err < gtol, (k, err)
+    if gtol is None:
+        # fp32: the reference itself is ~3e-2 away from its own float64 run on a few tensors
+        assert worst < 0.15, worst
+    for k in (kk for kk in ctx.new_buffers if not kk.endswith("num_batches_tracked")):
+        err, _ = G.compare(z, "buf/" + k, ctx.new_buffers[k].numpy(), 512)
+        assert err < max(tol, 1e-4), (k, err)
+    nbt = z["scalars/nbt_first_last"]
+    assert int(ctx.new_buffers["base.inc.conv.conv.down_conv_0.conv.1.num_batches_tracked"]) == nbt[0]
+    assert int(ctx.new_buffers["decoder.bone.upAtten4.UpAtten.conv1.1.num_batches_tracked"]) == nbt[1]
+    assert int(ctx.new_buffers["decoder.attend.bn.num_batches_tracked"]) == nbt[2]
+
+
+def test_train_256_scalars(golden_dir):
+    z = load(golden_dir, "train_256")
+    P, ctx, st, out, _ = run_with_gt(z, torch.float32, training=True)
+    for k in ("criterion", "ins_ce_loss", "ins_dice_loss"):
+        ref = float(z["scalars/" + k][0])
+        assert abs(float(out[k]) - ref) <= 2e-5 * max(1.0, abs(ref)), k
+    for nm in ("unet.x_dec", "x_enc", "attend.pro_split", "it1.L4.pred"):
+        err, _ = G.compare(z, nm, ctx.taps[nm].detach().numpy())
+        assert err < 5e-4, (nm, err)
+
+
+def test_byname_attention_ops(golden_dir):
+    z = load(golden_dir, "byname_ops")
+    t = lambda k: torch.from_numpy(z[k])
+    out, attn = R.sdp_attention(t("sdp/q"), t("sdp/k"), t("sdp/v"), float(np.sqrt(12.0)), t("sdp/mask"))
+    assert torch.allclose(out, t("sdp/out"), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(attn, t("sdp/attn"), rtol=1e-5, atol=1e-7)
+    QK, V = t("local/QK"), t("local/V")
+    nomask = t("local/nomask").repeat(2, 1, 1, 1)
+    att = R.local_dilated_attention(QK[:, :12], QK[:, 12:], V, nomask, int(z["local/dilation"][0]))
+    b2, dv, h, w = att.shape
+    # reference re-interleaves heads: [(b*head), dv, h, w] -> view [b, head*dv, h, w] (utils.py:300)
+    att = att.permute(0, 2, 3, 1).reshape(b2, h, w, dv).permute(0, 3, 1, 2).reshape(b2 // 2, 2 * dv, h, w)
+    assert torch.allclose(att, t("local/att"), rtol=1e-5, atol=1e-6)
+    pq = R.point_query_mask(t("pq/q"), t("pq/enc"))
+    assert torch.allclose(pq, t("pq/out"), rtol=1e-5, atol=1e-6)
