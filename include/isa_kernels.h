@@ -1,0 +1,168 @@
+/*
+ * isa_kernels.h — C-ABI of the MI355X (gfx950) kernel library for the ReSeg hot path.
+ *
+ * The reference (Snoworday/instance-segmentation-attention) has no FFI: its boundary is the Python
+ * class `ReSeg` (code/lib/archs/reseg.py:52-130) whose layers dispatch to torch/cuDNN.  This header
+ * is the layer the drop-in `ReSeg` class calls instead; each entry point names
+ * the reference operator(s) it replaces.  Conventions:
+ *   - plain C, no torch types; the caller owns every buffer (activations, parameters, scratch);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     never synchronises, so a whole step can be captured into a hipGraph;
+ *   - return 0 on success, a negative ISA_E* code on argument errors (nothing is launched then);
+ *   - activations are NHWC "views": element (b,y,x,c) lives at data[((b*h+y)*w+x)*ld + c], so
+ *     channel concatenation is done by writing into a slice of a wider buffer (reseg/unet `cat`);
+ *   - an input may be LAZY: its true value is act(scale[c]*raw+shift[c])*bscale[b][c] (isa_pro).
+ *     That is how train-mode BatchNorm+ReLU6 (137 BN modules) costs no extra pass over HBM: the
+ *     producer writes raw conv output and per-channel sum/sumsq, isa_bn_finalize turns those into
+ *     scale/shift, the consumer applies them while loading.
+ */
+#ifndef ISA_KERNELS_H
+#define ISA_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ISA_F32 = 0, ISA_BF16 = 1 };
+enum { ISA_ACT_NONE = 0, ISA_ACT_RELU = 1, ISA_ACT_RELU6 = 2, ISA_ACT_LEAKY = 3, ISA_ACT_TANH = 4 };
+enum { ISA_OK = 0, ISA_EINVAL = -1, ISA_EALIGN = -2, ISA_EDTYPE = -3, ISA_ELAUNCH = -4 };
+
+/* conv_gemm input addressing */
+enum { ISA_IN_1X1 = 0,       /* K = Cin                       (nn.Conv2d k=1)                    */
+       ISA_IN_3X3 = 1,       /* K = 9*Cin, zero pad 1         (nn.Conv2d k=3 p=1, dense)         */
+       ISA_IN_GATHER2 = 2 }; /* K = 4*Cin, tap (dy,dx) reads pixel (2y+dy,2x+dx) of a 2x image
+                                (data-gradient of ConvTranspose2d k=2 s=2)                       */
+/* conv_gemm output addressing */
+enum { ISA_OUT_PLAIN = 0,
+       ISA_OUT_SHUFFLE2 = 1 }; /* N = 4*Cout, column (dy,dx,co) goes to pixel (2y+dy,2x+dx)
+                                  (forward of ConvTranspose2d k=2 s=2)                          */
+
+typedef struct isa_tensor {
+    void*   data;   /* device pointer to element (0,0,0,0) of the view */
+    int32_t n, h, w;
+    int32_t c;      /* channels in the view */
+    int32_t ld;     /* pixel stride in elements (>= c) */
+    int32_t dtype;  /* ISA_F32 | ISA_BF16 */
+} isa_tensor;
+
+typedef struct isa_pro {       /* lazy-input prologue; all pointers may be NULL */
+    const float* scale;        /* [c]   */
+    const float* shift;        /* [c]   */
+    const float* bscale;       /* [n,c] per-image channel multiplier (Dropout2d mask, SE gate) */
+    int32_t      act;          /* ISA_ACT_* applied after the affine, before bscale */
+} isa_pro;
+
+typedef struct isa_pack_entry { /* one parameter tensor to repack (see isa_pack_weights) */
+    int64_t src_off;            /* element offset into the fp32 master buffer */
+    int64_t dst_off;            /* element offset into the packed buffer */
+    int32_t kind;               /* 0 conv fwd   src[N][K][taps]  -> dst[rows=N][taps][kp]
+                                   1 conv dgrad src[N][K][taps]  -> dst[rows=Kphys][taps flipped][kp>=N]
+                                   2 convT fwd  src[K][Co][2][2] -> dst[rows=4*Co][kp]      (n = Co)
+                                   3 convT dgrad                 -> dst[rows=Kphys][4][kp>=Co] (n = Co)
+                                   4 depthwise  src[C][1][3][3]  -> dst[9][rows]            (n = C)
+                                   5 depthwise, taps flipped (data gradient)                        */
+    int32_t n, k, taps;         /* logical dims of the source tensor */
+    int32_t kp;                 /* padded contraction length per tap in the destination (%32==0) */
+    int32_t kmap_off;           /* >=0: offset into kmap[] giving, per destination channel of the
+                                   K axis (kinds 0,2: contraction index; kinds 1,3: row; kinds 4,5:
+                                   column), the source channel or -1 for zero: channel padding and
+                                   concat reordering.  <0: identity */
+    int32_t rows;               /* destination rows (see kind) */
+} isa_pack_entry;
+
+/* ---- parameter repacking -------------------------------------------------------------------
+ * One launch repacks every conv weight from the reference's NCHW fp32 `state_dict` layout into
+ * the MFMA-operand layouts (row = output channel, contiguous contraction, zero padded to 32). */
+int isa_pack_weights(const isa_pack_entry* table_dev, int32_t n_entries, const int32_t* kmap_dev,
+                     const float* src_base, void* dst_base, int32_t dst_dtype, void* stream);
+
+/* ---- convolution as MFMA GEMM ----------------------------------------------------------------
+ * y[M=n*h*w, N] (+)= pro(x)[M, K] * W^T (+ bias).  Replaces nn.Conv2d k=1 / k=3 dense and
+ * nn.ConvTranspose2d(k=2,s=2) forward and their data-gradients (MobileNetDenseASPP.py:68-123 1x1
+ * convs, utils.py:703-707 L0Layer, unet_parts.py:73 / utils.py:975 up-convs, reseg.py:73 head).
+ * w: packed weights from isa_pack_weights ([Nrows][taps][kp], dtype = x.dtype).
+ * stats: optional float[2*N]; per-channel sum and sum of squares of the fp32 result are atomically
+ *        added (train-mode BatchNorm statistics fused into the producer).
+ * accumulate != 0: y += result (gradient accumulation for multi-consumer tensors).            */
+int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
+                  const float* bias, const isa_tensor* y, int32_t in_mode, int32_t out_mode,
+                  float* stats, int32_t accumulate, void* stream);
+
+/* Weight gradient of the same family, accumulated (fp32 atomics) straight into the reference's
+ * state_dict layout: dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)
+ *   += sum_m dy[m,n] * pro(x)[m@tap, kd],  kd -> k through kmap (NULL = identity, -1 = padding).
+ * dbias[N] += sum_m dy (optional, not for SHUFFLE2: use isa_colsum).                           */
+int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
+                   float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
+                   const int32_t* kmap, int32_t ksrc, void* stream);
+/* out[c] += sum over all pixels of x[.,c]  (bias gradients) */
+int isa_colsum(const isa_tensor* x, float* out, void* stream);
+
+/* ---- depthwise 3x3, pad 1 (MobileNetDenseASPP.py:77,109; reseg.py:79,93) ---------------------
+ * y = dw3x3(pro(x)) (+bias); w packed [9][C] (kind 4); stats as above.                         */
+int isa_dwconv3x3(const isa_tensor* x, const isa_pro* pro, const void* w, const float* bias,
+                  const isa_tensor* y, float* stats, void* stream);
+/* dx (+)= dw3x3^T(dy): w = tap-flipped packing (kind 5).
+ * wgrad: dw[C][1][3][3] (reference layout) += sum dy * pro(x) shifted; dbias += sum dy; only the
+ * first csrc channels are real parameters (the 21-channel input is padded to 24).              */
+int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const isa_tensor* dx,
+                        int32_t accumulate, void* stream);
+int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
+                        float* dw, float* dbias, int32_t csrc, void* stream);
+
+/* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
+ * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the
+ * backward); updates running_mean/var (momentum, unbiased var) when running_* != NULL.
+ * eval mode: pass stats == NULL and scale/shift are derived from running_*.                    */
+int isa_bn_finalize(const float* stats, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* mean, float* invstd, int32_t c,
+                    void* stream);
+/* backward of t = act(scale*y+shift): reduce pass  red[2C] += (sum dz, sum dz*yhat),
+ * then apply pass  dy = gamma*invstd*(dz - red0/count - yhat*red1/count)  (in place over dt ok) */
+int isa_bn_bwd_reduce(const isa_tensor* dt, const isa_tensor* y, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, int32_t act,
+                      const float* bscale, float* red, void* stream);
+int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, int32_t act,
+                     const float* bscale, const float* gamma, const float* red, float count,
+                     int32_t train, const isa_tensor* dy, float* dgamma, float* dbeta,
+                     void* stream);
+
+/* ---- materialise a lazy tensor: out = pro(x) (+ res)  (residual adds of Inverted*Residual,
+ * F.dropout2d, torch.cat placement) and its backward pieces ----------------------------------- */
+int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
+                       const isa_tensor* out, void* stream);
+/* dst (+)= src  (NHWC views; gradient fan-in of residual/skip connections) */
+int isa_axpy(const isa_tensor* src, const isa_tensor* dst, float alpha, int32_t accumulate,
+             void* stream);
+
+/* ---- pooling / resampling ------------------------------------------------------------------ */
+/* 2x2 mean, stride 2 == F.interpolate(scale=0.5,bilinear) on even sizes (unet_parts.py:58) */
+int isa_avgpool2(const isa_tensor* x, const isa_tensor* y, void* stream);
+int isa_avgpool2_bwd(const isa_tensor* dy, const isa_tensor* dx, int32_t accumulate, void* stream);
+/* f x f max / mean pooling with stride f of small-channel maps (utils.py:841-846) */
+int isa_pool_f(const isa_tensor* x, const isa_tensor* y, int32_t f, int32_t is_max, void* stream);
+/* 3x3 mean, stride 1, pad 1, count_include_pad (utils.py:634,645); optional per-pixel mask mul */
+int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* y, void* stream);
+
+/* ---- squeeze-excite gate + heads (utils.py:402-420, reseg.py:72-75,116-120) ------------------ */
+/* mean over h*w of pro(x): out[n,c] */
+int isa_chan_mean(const isa_tensor* x, const isa_pro* pro, float* out, void* stream);
+/* gate[n,c] = sigmoid(W2 relu(W1 m + b1) + b2); hidden/intermediates kept for backward */
+int isa_se_fc(const float* mean, const float* w1, const float* b1, const float* w2,
+              const float* b2, int32_t n, int32_t c, int32_t hidden, float* hid, float* gate,
+              void* stream);
+/* argmax over channels -> float map in {0..c-1} (first max wins, torch.argmax) */
+int isa_chan_argmax(const isa_tensor* x, const isa_tensor* y, void* stream);
+
+/* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
+int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
+int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISA_KERNELS_H */

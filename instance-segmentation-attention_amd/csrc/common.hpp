@@ -1,0 +1,134 @@
+// Shared device/host helpers for the gfx950 kernel library.  CDNA4 only: 64-wide wavefronts,
+// MFMA 32x32 tiles, 160 KB LDS/CU.  No portability macros on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/isa_kernels.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ISA_WAVE 64
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int launch_status() {
+    return hipGetLastError() == hipSuccess ? ISA_OK : ISA_ELAUNCH;
+}
+
+static inline bool tensor_ok(const isa_tensor* t, int align_elems) {
+    if (!t || !t->data || t->n <= 0 || t->h <= 0 || t->w <= 0 || t->c <= 0 || t->ld < t->c) return false;
+    if (t->dtype != ISA_F32 && t->dtype != ISA_BF16) return false;
+    if (align_elems > 1) {
+        size_t esz = t->dtype == ISA_F32 ? 4 : 2;
+        if ((reinterpret_cast<uintptr_t>(t->data) % (align_elems * esz)) != 0) return false;
+        if (t->ld % align_elems) return false;
+    }
+    return true;
+}
+
+// ---- storage-type traits --------------------------------------------------------------------
+template <typename T> struct st;
+template <> struct st<float> {
+    static constexpr int dtype = ISA_F32;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+};
+template <> struct st<bf16_t> {
+    static constexpr int dtype = ISA_BF16;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void stv(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// 8 consecutive elements <-> 8 floats (16 B for bf16, 2 x 16 B for f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+// guarded forms: only the first `nv` (1..8) elements exist (channel tail of a view); the full-vector
+// fast path is taken when nv == 8
+template <typename T> __device__ __forceinline__ void load8g(const T* p, float (&v)[8], int nv) {
+    if (nv >= 8) { load8<T>(p, v); return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < nv ? st<T>::ld(p + i) : 0.f;
+}
+template <typename T> __device__ __forceinline__ void store8g(T* p, const float (&v)[8], int nv) {
+    if (nv >= 8) { store8<T>(p, v); return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < nv) st<T>::stv(p + i, v[i]);
+}
+
+// ---- activations ----------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float z, int act) {
+    switch (act) {
+        case ISA_ACT_RELU:  return fmaxf(z, 0.f);
+        case ISA_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+        case ISA_ACT_LEAKY: return z > 0.f ? z : 0.01f * z;
+        case ISA_ACT_TANH:  return tanhf(z);
+        default:            return z;
+    }
+}
+// derivative w.r.t. the pre-activation z (torch semantics: relu6/hardtanh grad is 1 on 0<z<6;
+// threshold_backward for relu: z>0)
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case ISA_ACT_RELU:  return z > 0.f ? 1.f : 0.f;
+        case ISA_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+        case ISA_ACT_LEAKY: return z > 0.f ? 1.f : 0.01f;
+        case ISA_ACT_TANH:  { float t = tanhf(z); return 1.f - t * t; }
+        default:            return 1.f;
+    }
+}
+
+// device-side copy of isa_pro with nulls normalised
+struct ProDev {
+    const float* scale; const float* shift; const float* bscale; int act;
+};
+static inline ProDev make_pro(const isa_pro* p) {
+    ProDev d{nullptr, nullptr, nullptr, ISA_ACT_NONE};
+    if (p) { d.scale = p->scale; d.shift = p->shift; d.bscale = p->bscale; d.act = p->act; }
+    return d;
+}
+static inline bool pro_trivial(const ProDev& p) {
+    return !p.scale && !p.shift && !p.bscale && p.act == ISA_ACT_NONE;
+}
+
+// ---- wave reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }

@@ -1,0 +1,622 @@
+// Streaming / reduction kernels around the convolutions: parameter repacking, BatchNorm finalize and
+// backward, lazy-tensor materialisation (+residual), pooling, squeeze-excite, channel argmax.
+// All are HBM-bound: 16-byte vectors per lane over the NHWC channel axis, consecutive lanes on
+// consecutive channel groups, grid-strided with ~8 workgroups per CU; per-channel reductions go
+// registers -> LDS float atomics -> one global atomic per channel per workgroup.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// weight repacking (one launch for the whole parameter set)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(const isa_pack_entry* tab, const int32_t* kmap, const float* src, T* dst) {
+    const isa_pack_entry e = tab[blockIdx.y];
+    const float* s = src + e.src_off;
+    T* d = dst + e.dst_off;
+    const int32_t* km = e.kmap_off >= 0 ? kmap + e.kmap_off : nullptr;
+    long total;
+    const int rows = e.rows;
+    switch (e.kind) {
+        case 0: case 1: total = (long)rows * e.taps * e.kp; break;
+        case 2: total = (long)rows * e.kp; break;
+        case 3: total = (long)rows * 4 * e.kp; break;
+        default: total = (long)9 * rows; break;
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (e.kind == 0) {               // [N][taps][kp] <- src[N][K][taps]
+            const int kd = (int)(i % e.kp); long q = i / e.kp;
+            const int t = (int)(q % e.taps); const int n = (int)(q / e.taps);
+            const int k = km ? km[kd] : (kd < e.k ? kd : -1);
+            if (k >= 0) v = s[((long)n * e.k + k) * e.taps + t];
+        } else if (e.kind == 1) {        // [rows=Kphys][taps][np] <- src[N][K][taps], taps flipped
+            const int nd = (int)(i % e.kp); long q = i / e.kp;
+            const int t = (int)(q % e.taps); const int kd = (int)(q / e.taps);
+            const int k = km ? km[kd] : kd;
+            if (k >= 0 && nd < e.n) v = s[((long)nd * e.k + k) * e.taps + (e.taps - 1 - t)];
+        } else if (e.kind == 2) {        // convT fwd: [4*Co][kp] <- src[K][Co][2][2]
+            const int kd = (int)(i % e.kp); const int row = (int)(i / e.kp);
+            const int co_n = e.n;        // Co
+            const int qd = row / co_n, co = row - qd * co_n;
+            const int k = km ? km[kd] : (kd < e.k ? kd : -1);
+            if (k >= 0) v = s[((long)k * co_n + co) * 4 + qd];
+        } else if (e.kind == 3) {        // convT dgrad: [K][4][cop] <- src[K][Co][2][2]
+            const int cod = (int)(i % e.kp); long q = i / e.kp;
+            const int qd = (int)(q % 4); const int kd = (int)(q / 4);
+            const int k = km ? km[kd] : kd;
+            if (k >= 0 && cod < e.n) v = s[((long)k * e.n + cod) * 4 + qd];
+        } else {                          // depthwise: [9][rows] <- src[C][9]; kind 5 = flipped
+            const int cd = (int)(i % rows); const int t = (int)(i / rows);
+            const int c = km ? km[cd] : (cd < e.n ? cd : -1);
+            if (c >= 0) v = s[(long)c * 9 + (e.kind == 5 ? 8 - t : t)];
+        }
+        d[i] = (T)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm finalize
+// ------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* stats, float count, const float* gamma,
+                                   const float* beta, float* rm, float* rv, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_o, float* invstd_o, int c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
+        float mean, var;
+        if (stats) {
+            mean = stats[i] / count;
+            var = fmaxf(stats[c + i] / count - mean * mean, 0.f);
+            if (rm) rm[i] = (1.f - momentum) * rm[i] + momentum * mean;
+            if (rv) rv[i] = (1.f - momentum) * rv[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        } else {
+            mean = rm[i]; var = rv[i];
+        }
+        const float inv = 1.0f / sqrtf(var + eps);
+        const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
+        scale[i] = g * inv;
+        shift[i] = b - mean * g * inv;
+        if (mean_o) mean_o[i] = mean;
+        if (invstd_o) invstd_o[i] = inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic vectorised NHWC walker
+// ------------------------------------------------------------------------------------------
+struct View { void* data; int n, h, w, c, ld; };
+static inline View mkview(const isa_tensor* t) { return View{t->data, t->n, t->h, t->w, t->c, t->ld}; }
+
+struct BnBwdParams {
+    View dt, y, dy;
+    const float *scale, *shift, *mean, *invstd, *bscale, *gamma, *red;
+    float* out_red; float* dgamma; float* dbeta;
+    float inv_count; int act, train;
+    long pixels; int cg;
+};
+
+// z = scale*y+shift ; dz = dt * bscale * act'(z)
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
+    extern __shared__ float red[];              // reduce pass: [2*C]
+    const int C = p.y.c;
+    if (!APPLY) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+        __syncthreads();
+    } else if (blockIdx.x == 0 && p.train) {
+        for (int i = threadIdx.x; i < C; i += 256) {
+            if (p.dgamma) atomicAdd(p.dgamma + i, p.red[C + i]);
+            if (p.dbeta) atomicAdd(p.dbeta + i, p.red[i]);
+        }
+    }
+    // threads of a block share the channel group pattern: item = pixel*cg + cgi
+    const long items = p.pixels * p.cg;
+    const long stride = (long)gridDim.x * 256;
+    // stride is a multiple of cg when 256 % cg == 0; otherwise recompute cgi per item
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    int last_c0 = -1;
+    float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
+    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += stride) {
+        const int cgi = (int)(item % p.cg);
+        const long pix = item / p.cg;
+        const int c0 = cgi * 8;
+        if (c0 != last_c0) {
+            if (!APPLY && last_c0 >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (last_c0 + j < C) { atomicAdd(&red[last_c0 + j], s0[j]); atomicAdd(&red[C + last_c0 + j], s1[j]); }
+                    s0[j] = 0.f; s1[j] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = min(c0 + j, C - 1);
+                sc[j] = p.scale ? p.scale[c] : 1.f;
+                sh[j] = p.shift ? p.shift[c] : 0.f;
+                mu[j] = p.mean ? p.mean[c] : 0.f;
+                is[j] = p.invstd ? p.invstd[c] : 1.f;
+                if (APPLY) {
+                    k0[j] = p.train ? p.red[c] * p.inv_count : 0.f;
+                    k1[j] = p.train ? p.red[C + c] * p.inv_count : 0.f;
+                }
+            }
+            last_c0 = c0;
+        }
+        const int b = (int)(pix / ((long)p.y.h * p.y.w));
+        float dt[8], yv[8];
+        const int nv = min(8, C - c0);
+        load8g<T>(reinterpret_cast<const T*>(p.dt.data) + pix * p.dt.ld + c0, dt, nv);
+        load8g<T>(reinterpret_cast<const T*>(p.y.data) + pix * p.y.ld + c0, yv, nv);
+        float out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = fmaf(yv[j], sc[j], sh[j]);
+            float dz = dt[j] * act_grad(z, p.act);
+            if (p.bscale) dz *= p.bscale[(long)b * C + min(c0 + j, C - 1)];
+            const float yh = (yv[j] - mu[j]) * is[j];
+            if (!APPLY) { s0[j] += dz; s1[j] += dz * yh; }
+            else out[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
+        }
+        if (APPLY) store8g<T>(reinterpret_cast<T*>(p.dy.data) + pix * p.dy.ld + c0, out, nv);
+    }
+    if (!APPLY) {
+        if (last_c0 >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (last_c0 + j < C) { atomicAdd(&red[last_c0 + j], s0[j]); atomicAdd(&red[C + last_c0 + j], s1[j]); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256)
+            if (red[i] != 0.f) atomicAdd(p.out_red + i, red[i]);
+    }
+}
+
+// out = pro(x) (+ res)
+struct MatParams { View x, res, out; ProDev pro; long pixels; int cg; int has_res; };
+template <typename T>
+__global__ __launch_bounds__(256) void materialize_kernel(MatParams p) {
+    const long items = p.pixels * p.cg;
+    const int C = p.x.c;
+    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+        const int c0 = (int)(item % p.cg) * 8;
+        const long pix = item / p.cg;
+        const int b = (int)(pix / ((long)p.x.h * p.x.w));
+        float v[8];
+        const int nv = min(8, C - c0);
+        load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, v, nv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(c0 + j, C - 1);
+            float z = v[j];
+            if (p.pro.scale) z *= p.pro.scale[c];
+            if (p.pro.shift) z += p.pro.shift[c];
+            z = act_apply(z, p.pro.act);
+            if (p.pro.bscale) z *= p.pro.bscale[(long)b * C + c];
+            v[j] = z;
+        }
+        if (p.has_res) {
+            float rr[8];
+            load8g<T>(reinterpret_cast<const T*>(p.res.data) + pix * p.res.ld + c0, rr, nv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+        store8g<T>(reinterpret_cast<T*>(p.out.data) + pix * p.out.ld + c0, v, nv);
+    }
+}
+
+struct AxpyParams { View src, dst; float alpha; int accumulate; long pixels; };
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(AxpyParams p) {
+    const int C = p.src.c;
+    const long items = p.pixels * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C); const long pix = i / C;
+        float v = p.alpha * st<T>::ld(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c);
+        T* d = reinterpret_cast<T*>(p.dst.data) + pix * p.dst.ld + c;
+        if (p.accumulate) v += st<T>::ld(d);
+        st<T>::stv(d, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void axpy8_kernel(AxpyParams p) {
+    const int cg = p.src.c / 8;
+    const long items = p.pixels * cg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * 8; const long pix = i / cg;
+        float v[8];
+        load8<T>(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c0, v);
+        T* d = reinterpret_cast<T*>(p.dst.data) + pix * p.dst.ld + c0;
+        if (p.accumulate) {
+            float o[8]; load8<T>(d, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(p.alpha, v[j], o[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+        }
+        store8<T>(d, v);
+    }
+}
+
+// 2x2 mean pooling and its backward
+struct PoolParams { View x, y; int accumulate; int f; int is_max; };
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void avgpool2_kernel(PoolParams p) {
+    // fwd: x big -> y small.  bwd: (x = dy small) -> (y = dx big), dx (+)= dy/4
+    const View big = BWD ? p.y : p.x, small = BWD ? p.x : p.y;
+    const int cg = small.c / 8;
+    const long items = (long)small.n * small.h * small.w * cg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * 8; long q = i / cg;
+        const int xs = (int)(q % small.w); q /= small.w;
+        const int ys = (int)(q % small.h); const int b = (int)(q / small.h);
+        T* sp = reinterpret_cast<T*>(small.data) + (((long)b * small.h + ys) * small.w + xs) * small.ld + c0;
+        T* bp = reinterpret_cast<T*>(big.data) + (((long)b * big.h + 2 * ys) * big.w + 2 * xs) * big.ld + c0;
+        if (!BWD) {
+            float a[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                load8<T>(bp + ((long)(d >> 1) * big.w + (d & 1)) * big.ld, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += a[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
+            store8<T>(sp, acc);
+        } else {
+            float g[8];
+            load8<T>(sp, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] *= 0.25f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                T* dp = bp + ((long)(d >> 1) * big.w + (d & 1)) * big.ld;
+                float o[8];
+                if (p.accumulate) {
+                    load8<T>(dp, o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += g[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = g[j];
+                }
+                store8<T>(dp, o);
+            }
+        }
+    }
+}
+
+// f x f pooling (stride f) of narrow maps; scalar per element
+template <typename T>
+__global__ __launch_bounds__(256) void pool_f_kernel(PoolParams p) {
+    const long items = (long)p.y.n * p.y.h * p.y.w * p.y.c;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % p.y.c); long q = i / p.y.c;
+        const int xo = (int)(q % p.y.w); q /= p.y.w;
+        const int yo = (int)(q % p.y.h); const int b = (int)(q / p.y.h);
+        float acc = p.is_max ? -INFINITY : 0.f;
+        for (int dy = 0; dy < p.f; ++dy)
+            for (int dx = 0; dx < p.f; ++dx) {
+                const float v = st<T>::ld(reinterpret_cast<const T*>(p.x.data) +
+                    (((long)b * p.x.h + yo * p.f + dy) * p.x.w + xo * p.f + dx) * p.x.ld + c);
+                acc = p.is_max ? fmaxf(acc, v) : acc + v;
+            }
+        if (!p.is_max) acc /= (float)(p.f * p.f);
+        st<T>::stv(reinterpret_cast<T*>(p.y.data) + (((long)b * p.y.h + yo) * p.y.w + xo) * p.y.ld + c, acc);
+    }
+}
+
+// 3x3 mean, stride 1, pad 1, divisor always 9; optional single-channel mask multiply
+struct Pool3Params { View x, mask, y; int has_mask; };
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3_kernel(Pool3Params p) {
+    const long items = (long)p.y.n * p.y.h * p.y.w * p.y.c;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % p.y.c); long q = i / p.y.c;
+        const int xo = (int)(q % p.y.w); q /= p.y.w;
+        const int yo = (int)(q % p.y.h); const int b = (int)(q / p.y.h);
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = yo + dy, xx = xo + dx;
+                if (yy >= 0 && yy < p.x.h && xx >= 0 && xx < p.x.w)
+                    acc += st<T>::ld(reinterpret_cast<const T*>(p.x.data) + (((long)b * p.x.h + yy) * p.x.w + xx) * p.x.ld + c);
+            }
+        acc *= (1.f / 9.f);
+        const long pix = ((long)b * p.y.h + yo) * p.y.w + xo;
+        if (p.has_mask) acc *= st<T>::ld(reinterpret_cast<const T*>(p.mask.data) + pix * p.mask.ld);
+        st<T>::stv(reinterpret_cast<T*>(p.y.data) + pix * p.y.ld + c, acc);
+    }
+}
+
+// per-(image,channel) mean of pro(x): grid = (blocks, n)
+struct MeanParams { View x; ProDev pro; float* out; float inv_hw; };
+template <typename T>
+__global__ __launch_bounds__(256) void chan_mean_kernel(MeanParams p) {
+    extern __shared__ float red[];            // [C]
+    const int C = p.x.c, cg = C / 8, b = blockIdx.y;
+    for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const long hw = (long)p.x.h * p.x.w, items = hw * cg;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int last_c0 = -1;
+    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
+        const int c0 = (int)(item % cg) * 8; const long pix = item / cg;
+        if (c0 != last_c0 && last_c0 >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&red[last_c0 + j], s[j]); s[j] = 0.f; }
+        }
+        last_c0 = c0;
+        float v[8];
+        load8<T>(reinterpret_cast<const T*>(p.x.data) + ((long)b * hw + pix) * p.x.ld + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = v[j];
+            if (p.pro.scale) z *= p.pro.scale[c0 + j];
+            if (p.pro.shift) z += p.pro.shift[c0 + j];
+            s[j] += act_apply(z, p.pro.act);
+        }
+    }
+    if (last_c0 >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&red[last_c0 + j], s[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256)
+        if (red[i] != 0.f) atomicAdd(p.out + (long)b * C + i, red[i] * p.inv_hw);
+}
+
+// SE gate: one workgroup per image
+__global__ void se_fc_kernel(const float* mean, const float* w1, const float* b1, const float* w2,
+                             const float* b2, int c, int hidden, float* hid, float* gate) {
+    extern __shared__ float sm[];             // [c + hidden]
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < c; i += blockDim.x) sm[i] = mean[(long)b * c + i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < hidden; j += blockDim.x) {
+        float a = b1[j];
+        for (int i = 0; i < c; ++i) a = fmaf(w1[j * c + i], sm[i], a);
+        a = fmaxf(a, 0.f);
+        sm[c + j] = a;
+        if (hid) hid[(long)b * hidden + j] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        float a = b2[i];
+        for (int j = 0; j < hidden; ++j) a = fmaf(w2[i * hidden + j], sm[c + j], a);
+        gate[(long)b * c + i] = 1.f / (1.f + expf(-a));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_argmax_kernel(View x, View y) {
+    const long pixels = (long)x.n * x.h * x.w;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < pixels; pix += (long)gridDim.x * 256) {
+        const T* px = reinterpret_cast<const T*>(x.data) + pix * x.ld;
+        float best = st<T>::ld(px); int bi = 0;
+        for (int c = 1; c < x.c; ++c) {
+            const float v = st<T>::ld(px + c);
+            if (v > best) { best = v; bi = c; }
+        }
+        st<T>::stv(reinterpret_cast<T*>(y.data) + pix * y.ld, (float)bi);
+    }
+}
+
+// boundary layout converters: the reference hands over NCHW fp32 tensors (reseg.py:106-110)
+template <typename T, bool TO_NHWC>
+__global__ __launch_bounds__(256) void layout_kernel(float* nchw, View v, int csrc) {
+    // NHWC-major indexing so the strided side is the fp32 NCHW one (read once / written once)
+    const long total = (long)v.n * v.h * v.w * v.c;
+    const long hw = (long)v.h * v.w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % v.c); const long pix = i / v.c;
+        const long b = pix / hw, sp = pix - b * hw;
+        T* q = reinterpret_cast<T*>(v.data) + pix * v.ld + c;
+        if (TO_NHWC) st<T>::stv(q, c < csrc ? nchw[(b * csrc + c) * hw + sp] : 0.f);
+        else if (c < csrc) nchw[(b * csrc + c) * hw + sp] = st<T>::ld(q);
+    }
+}
+
+static inline bool same_shape(const isa_tensor* a, const isa_tensor* b) {
+    return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+    do { if ((dtype) == ISA_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int isa_pack_weights(const isa_pack_entry* table_dev, int32_t n_entries,
+                                const int32_t* kmap_dev, const float* src_base, void* dst_base,
+                                int32_t dst_dtype, void* stream) {
+    if (!table_dev || n_entries <= 0 || !src_base || !dst_base) return ISA_EINVAL;
+    dim3 grid(32, n_entries);
+    DISPATCH_T(dst_dtype,
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), table_dev, kmap_dev, src_base, (bf16_t*)dst_base),
+        hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, as_stream(stream), table_dev, kmap_dev, src_base, (float*)dst_base));
+    return launch_status();
+}
+
+extern "C" int isa_bn_finalize(const float* stats, float count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, float* scale, float* shift,
+                               float* mean, float* invstd, int32_t c, void* stream) {
+    if (c <= 0 || !scale || !shift || (!stats && (!running_mean || !running_var))) return ISA_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), stats, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, c);
+    return launch_status();
+}
+
+static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_tensor* dy,
+                         BnBwdParams& p, bool apply, void* stream) {
+    if (!tensor_ok(dt, 8) || !tensor_ok(y, 8) || !same_shape(dt, y)) return ISA_EINVAL;
+    p.dt = mkview(dt); p.y = mkview(y);
+    if (apply) { if (!tensor_ok(dy, 8) || !same_shape(dy, y)) return ISA_EINVAL; p.dy = mkview(dy); }
+    p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
+    const int grid = grid_cap(cdiv(p.pixels * p.cg, 256));
+    const size_t lds = apply ? 0 : 2 * (size_t)y->c * 4;
+    if (apply)
+        DISPATCH_T(y->dtype,
+            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), lds, as_stream(stream), p),
+            hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(256), lds, as_stream(stream), p));
+    else
+        DISPATCH_T(y->dtype,
+            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), lds, as_stream(stream), p),
+            hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(256), lds, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_bn_bwd_reduce(const isa_tensor* dt, const isa_tensor* y, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd,
+                                 int32_t act, const float* bscale, float* red, void* stream) {
+    if (!red) return ISA_EINVAL;
+    BnBwdParams p{};
+    p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.bscale = bscale;
+    p.act = act; p.out_red = red; p.train = 1;
+    return bn_bwd_common(dt, y, nullptr, p, false, stream);
+}
+
+extern "C" int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const float* scale,
+                                const float* shift, const float* mean, const float* invstd,
+                                int32_t act, const float* bscale, const float* gamma,
+                                const float* red, float count, int32_t train,
+                                const isa_tensor* dy, float* dgamma, float* dbeta, void* stream) {
+    if (train && !red) return ISA_EINVAL;
+    BnBwdParams p{};
+    p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.bscale = bscale;
+    p.gamma = gamma; p.red = red; p.inv_count = count > 0 ? 1.f / count : 0.f;
+    p.act = act; p.train = train; p.dgamma = dgamma; p.dbeta = dbeta;
+    return bn_bwd_common(dt, y, dy, p, true, stream);
+}
+
+extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
+                                  const isa_tensor* out, void* stream) {
+    if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !same_shape(x, out)) return ISA_EINVAL;
+    if (res && (!tensor_ok(res, 8) || !same_shape(res, x))) return ISA_EINVAL;
+    MatParams p{};
+    p.x = mkview(x); p.out = mkview(out); p.pro = make_pro(pro); p.has_res = res != nullptr;
+    if (res) p.res = mkview(res);
+    p.pixels = (long)x->n * x->h * x->w; p.cg = (x->c + 7) / 8;
+    const int grid = grid_cap(cdiv(p.pixels * p.cg, 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(materialize_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
+        hipLaunchKernelGGL(materialize_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_axpy(const isa_tensor* src, const isa_tensor* dst, float alpha,
+                        int32_t accumulate, void* stream) {
+    if (!tensor_ok(src, 1) || !tensor_ok(dst, 1) || !same_shape(src, dst)) return ISA_EINVAL;
+    AxpyParams p{mkview(src), mkview(dst), alpha, accumulate, (long)src->n * src->h * src->w};
+    const bool vec = tensor_ok(src, 8) && tensor_ok(dst, 8) && src->c % 8 == 0;
+    const int grid = grid_cap(cdiv(p.pixels * (vec ? src->c / 8 : src->c), 256));
+    if (vec)
+        DISPATCH_T(src->dtype,
+            hipLaunchKernelGGL(axpy8_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
+            hipLaunchKernelGGL(axpy8_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+    else
+        DISPATCH_T(src->dtype,
+            hipLaunchKernelGGL(axpy_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
+            hipLaunchKernelGGL(axpy_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_avgpool2(const isa_tensor* x, const isa_tensor* y, void* stream) {
+    if (!tensor_ok(x, 8) || !tensor_ok(y, 8) || x->dtype != y->dtype || x->c != y->c || x->c % 8 ||
+        x->n != y->n || x->h != 2 * y->h || x->w != 2 * y->w) return ISA_EINVAL;
+    PoolParams p{mkview(x), mkview(y), 0, 2, 0};
+    const int grid = grid_cap(cdiv((long)y->n * y->h * y->w * (y->c / 8), 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL((avgpool2_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, as_stream(stream), p),
+        hipLaunchKernelGGL((avgpool2_kernel<float, false>), dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_avgpool2_bwd(const isa_tensor* dy, const isa_tensor* dx, int32_t accumulate,
+                                void* stream) {
+    if (!tensor_ok(dy, 8) || !tensor_ok(dx, 8) || dy->dtype != dx->dtype || dy->c != dx->c ||
+        dy->c % 8 || dy->n != dx->n || dx->h != 2 * dy->h || dx->w != 2 * dy->w) return ISA_EINVAL;
+    PoolParams p{mkview(dy), mkview(dx), accumulate, 2, 0};
+    const int grid = grid_cap(cdiv((long)dy->n * dy->h * dy->w * (dy->c / 8), 256));
+    DISPATCH_T(dy->dtype,
+        hipLaunchKernelGGL((avgpool2_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, as_stream(stream), p),
+        hipLaunchKernelGGL((avgpool2_kernel<float, true>), dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_pool_f(const isa_tensor* x, const isa_tensor* y, int32_t f, int32_t is_max,
+                          void* stream) {
+    if (!tensor_ok(x, 1) || !tensor_ok(y, 1) || x->dtype != y->dtype || x->c != y->c || f < 1 ||
+        x->n != y->n || x->h != f * y->h || x->w != f * y->w) return ISA_EINVAL;
+    PoolParams p{mkview(x), mkview(y), 0, f, is_max};
+    const int grid = grid_cap(cdiv((long)y->n * y->h * y->w * y->c, 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(pool_f_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
+        hipLaunchKernelGGL(pool_f_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* y,
+                            void* stream) {
+    if (!tensor_ok(x, 1) || !tensor_ok(y, 1) || !same_shape(x, y)) return ISA_EINVAL;
+    if (mask && (!tensor_ok(mask, 1) || mask->n != x->n || mask->h != x->h || mask->w != x->w ||
+                 mask->dtype != x->dtype)) return ISA_EINVAL;
+    Pool3Params p{mkview(x), mask ? mkview(mask) : View{}, mkview(y), mask != nullptr};
+    const int grid = grid_cap(cdiv((long)y->n * y->h * y->w * y->c, 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(avgpool3_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
+        hipLaunchKernelGGL(avgpool3_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_chan_mean(const isa_tensor* x, const isa_pro* pro, float* out, void* stream) {
+    if (!tensor_ok(x, 8) || x->c % 8 || !out) return ISA_EINVAL;
+    MeanParams p{mkview(x), make_pro(pro), out, 1.f / ((float)x->h * x->w)};
+    const long items = (long)x->h * x->w * (x->c / 8);
+    dim3 grid(grid_cap(cdiv(items, 256), 128), x->n);
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(chan_mean_kernel<bf16_t>, grid, dim3(256), x->c * 4, as_stream(stream), p),
+        hipLaunchKernelGGL(chan_mean_kernel<float>, grid, dim3(256), x->c * 4, as_stream(stream), p));
+    return launch_status();
+}
+
+extern "C" int isa_se_fc(const float* mean, const float* w1, const float* b1, const float* w2,
+                         const float* b2, int32_t n, int32_t c, int32_t hidden, float* hid,
+                         float* gate, void* stream) {
+    if (!mean || !w1 || !b1 || !w2 || !b2 || !gate || n <= 0 || c <= 0 || hidden <= 0) return ISA_EINVAL;
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(64), (c + hidden) * 4, as_stream(stream), mean, w1, b1,
+                       w2, b2, c, hidden, hid, gate);
+    return launch_status();
+}
+
+extern "C" int isa_chan_argmax(const isa_tensor* x, const isa_tensor* y, void* stream) {
+    if (!tensor_ok(x, 1) || !tensor_ok(y, 1) || x->dtype != y->dtype || x->n != y->n ||
+        x->h != y->h || x->w != y->w) return ISA_EINVAL;
+    const int grid = grid_cap(cdiv((long)x->n * x->h * x->w, 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(chan_argmax_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(x), mkview(y)),
+        hipLaunchKernelGGL(chan_argmax_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(x), mkview(y)));
+    return launch_status();
+}
+
+extern "C" int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream) {
+    if (!src || !tensor_ok(dst, 1) || csrc <= 0 || csrc > dst->c) return ISA_EINVAL;
+    const int grid = grid_cap(cdiv((long)dst->n * dst->h * dst->w * dst->c, 256));
+    DISPATCH_T(dst->dtype,
+        hipLaunchKernelGGL((layout_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)src, mkview(dst), csrc),
+        hipLaunchKernelGGL((layout_kernel<float, true>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)src, mkview(dst), csrc));
+    return launch_status();
+}
+
+extern "C" int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream) {
+    if (!dst || !tensor_ok(src, 1)) return ISA_EINVAL;
+    const int grid = grid_cap(cdiv((long)src->n * src->h * src->w * src->c, 256));
+    DISPATCH_T(src->dtype,
+        hipLaunchKernelGGL((layout_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, mkview(src), src->c),
+        hipLaunchKernelGGL((layout_kernel<float, false>), dim3(grid), dim3(256), 0, as_stream(stream), dst, mkview(src), src->c));
+    return launch_status();
+}

@@ -1,0 +1,561 @@
+"""Host-side engine: NHWC activation views, static arena, parameter store, op wrappers + tape.
+
+Python orchestrates, the C-ABI library computes.  Everything an op needs lives in buffers that are
+allocated once per (shape, mode) and reused every step, so a whole forward/backward/update step
+is a fixed sequence of asynchronous launches on one HIP stream and can be captured in a hipGraph
+(see trainer.py).  torch is used for: device memory, streams, events, RCCL.  Not for math.
+
+Gradient convention: `Act.grad` is the gradient w.r.t. the TRUE value of the activation (after its
+lazy prologue).  Multi-consumer tensors accumulate: the first backward writer overwrites, later
+writers add (tracked per buffer and channel range) — no memsets of activation-sized buffers.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Pro:
+    """Lazy prologue: value = act(scale*raw + shift) * bscale."""
+    __slots__ = ("scale", "shift", "bscale", "act", "_c")
+
+    def __init__(self, scale=None, shift=None, act=L.ACT_NONE, bscale=None):
+        self.scale, self.shift, self.act, self.bscale = scale, shift, act, bscale
+        self._c = L.IsaPro(L.ptr(scale), L.ptr(shift), L.ptr(bscale), act)
+
+    def c(self):
+        return C.byref(self._c)
+
+
+class Act:
+    """A channel slice [c0, c0+c) of an NHWC buffer [n,h,w,ld]."""
+    __slots__ = ("buf", "c0", "c", "pro", "_c", "needs_grad", "bn")
+
+    def __init__(self, buf: torch.Tensor, c0=0, c=None, pro: Optional[Pro] = None, needs_grad=True):
+        assert buf.dim() == 4 and buf.is_contiguous()
+        self.buf, self.c0 = buf, c0
+        self.c = buf.shape[3] - c0 if c is None else c
+        assert 0 <= c0 and c0 + self.c <= buf.shape[3]
+        self.pro = pro
+        self.needs_grad = needs_grad
+        self.bn = None
+        n, h, w, ld = buf.shape
+        self._c = L.IsaTensor(buf.data_ptr() + c0 * buf.element_size(), n, h, w, self.c, ld,
+                              L.dtype_code(buf.dtype))
+
+    n = property(lambda s: s.buf.shape[0])
+    h = property(lambda s: s.buf.shape[1])
+    w = property(lambda s: s.buf.shape[2])
+    ld = property(lambda s: s.buf.shape[3])
+
+    def d(self):
+        return C.byref(self._c)
+
+    def p(self):
+        return self.pro.c() if self.pro is not None else None
+
+    def slice(self, c0, c, pro=None):
+        return Act(self.buf, self.c0 + c0, c, pro, self.needs_grad)
+
+    def with_pro(self, pro):
+        a = Act(self.buf, self.c0, self.c, pro, self.needs_grad)
+        return a
+
+    def nchw(self) -> torch.Tensor:
+        """Materialised copy as NCHW float32 (tests / outputs only; applies no prologue)."""
+        return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
+
+
+class Arena:
+    """Bump allocator whose allocations are replayed in the same order every step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.slots: List[torch.Tensor] = []
+        self.cursor = 0
+
+    def reset(self):
+        self.cursor = 0
+
+    def alloc(self, shape, dtype, zero=False):
+        shape = tuple(int(s) for s in shape)
+        if self.cursor < len(self.slots):
+            t = self.slots[self.cursor]
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                # shape changed (new batch/size): drop the tail and start recording again
+                del self.slots[self.cursor:]
+                t = None
+        else:
+            t = None
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.slots.append(t)
+        self.cursor += 1
+        if zero:
+            t.zero_()
+        return t
+
+    def bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.slots)
+
+
+class ParamStore:
+    """All parameters and float buffers in ONE flat fp32 tensor (reference state_dict layout per
+    tensor) and their gradients in another: one RCCL all-reduce, one optimizer kernel."""
+
+    def __init__(self, schema: List[Tuple[str, tuple]], device):
+        self.device = device
+        self.names = [n for n, _ in schema]
+        self.shapes = {n: tuple(s) for n, s in schema}
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        self.int_buffers: Dict[str, int] = {}
+        for n, s in schema:
+            if n.endswith("num_batches_tracked"):
+                self.int_buffers[n] = 0
+                continue
+            self.offsets[n] = off
+            numel = 1
+            for d in s:
+                numel *= d
+            off += rup(numel, 4)          # keep every tensor 16-byte aligned
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def numel(self, name):
+        n = 1
+        for d in self.shapes[name]:
+            n *= d
+        return n
+
+    def view(self, name):
+        o = self.offsets[name]
+        return self.flat[o:o + self.numel(name)].view(self.shapes[name])
+
+    def gview(self, name):
+        o = self.offsets[name]
+        return self.grad[o:o + self.numel(name)].view(self.shapes[name])
+
+    def ptr(self, name):
+        return C.c_void_p(self.flat.data_ptr() + 4 * self.offsets[name])
+
+    def gptr(self, name):
+        return C.c_void_p(self.grad.data_ptr() + 4 * self.offsets[name])
+
+    def load_state_dict(self, sd):
+        for n in self.names:
+            if n in self.int_buffers:
+                if n in sd:
+                    self.int_buffers[n] = int(sd[n])
+                continue
+            if n in sd:
+                self.view(n).copy_(sd[n].to(torch.float32))
+
+    def state_dict(self):
+        out = {}
+        for n in self.names:
+            if n in self.int_buffers:
+                out[n] = torch.tensor(self.int_buffers[n], dtype=torch.long)
+            else:
+                out[n] = self.view(n).detach().clone()
+        return out
+
+
+class Packer:
+    """Table of weight repack jobs (isa_pack_weights).  Keys are (param name, variant)."""
+
+    def __init__(self, params: ParamStore, dtype):
+        self.params, self.dtype = params, dtype
+        self.entries: List[dict] = []
+        self.index: Dict[tuple, dict] = {}
+        self.kmaps: List[int] = []
+        self.total = 0
+        self.buf = None
+        self.table = None
+        self.kmap_dev = None
+
+    def add(self, name, variant, kind, n, k, taps, kp, rows, kmap=None):
+        key = (name, variant)
+        if key in self.index:
+            return key
+        kmap_off = -1
+        if kmap is not None:
+            kmap_off = len(self.kmaps)
+            self.kmaps.extend(int(v) for v in kmap)
+        if kind in (0, 1):
+            size = rows * taps * kp
+        elif kind == 2:
+            size = rows * kp
+        elif kind == 3:
+            size = rows * 4 * kp
+        else:
+            size = 9 * rows
+        e = dict(name=name, kind=kind, n=n, k=k, taps=taps, kp=kp, rows=rows, kmap_off=kmap_off,
+                 dst_off=self.total, size=size, kmap_len=0 if kmap is None else len(kmap))
+        self.total += rup(size, 16)
+        self.entries.append(e)
+        self.index[key] = e
+        self.table = None
+        return key
+
+    def finalize(self):
+        dev = self.params.device
+        if self.buf is None or self.buf.numel() < self.total:
+            self.buf = torch.zeros(max(self.total, 16), dtype=self.dtype, device=dev)
+        arr = (L.IsaPackEntry * len(self.entries))()
+        for i, e in enumerate(self.entries):
+            arr[i] = L.IsaPackEntry(self.params.offsets[e["name"]], e["dst_off"], e["kind"], e["n"],
+                                    e["k"], e["taps"], e["kp"], e["kmap_off"], e["rows"])
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        km = self.kmaps if self.kmaps else [0]
+        self.kmap_dev = torch.tensor(km, dtype=torch.int32, device=dev)
+
+    def pack(self):
+        if self.table is None:
+            self.finalize()
+        L.check(L.lib().isa_pack_weights(L.ptr(self.table), len(self.entries), L.ptr(self.kmap_dev),
+                                         L.ptr(self.params.flat), L.ptr(self.buf),
+                                         L.dtype_code(self.dtype), L.stream_ptr()), "isa_pack_weights")
+
+    def ptr(self, key):
+        e = self.index[key]
+        return C.c_void_p(self.buf.data_ptr() + e["dst_off"] * self.buf.element_size())
+
+    def kmap_ptr(self, key):
+        e = self.index[key]
+        if e["kmap_off"] < 0:
+            return None
+        return C.c_void_p(self.kmap_dev.data_ptr() + 4 * e["kmap_off"])
+
+
+class GradBook:
+    """Gradient buffers mirror activation buffers; tracks which channel ranges were written."""
+
+    def __init__(self, arena: Arena):
+        self.arena = arena
+        self.bufs: Dict[int, torch.Tensor] = {}
+        self.written: Dict[int, List[Tuple[int, int]]] = {}
+
+    def reset(self):
+        self.bufs.clear()
+        self.written.clear()
+
+    def grad_of(self, a: Act) -> Act:
+        key = a.buf.data_ptr()
+        g = self.bufs.get(key)
+        if g is None:
+            g = self.arena.alloc(a.buf.shape, a.buf.dtype)
+            self.bufs[key] = g
+            self.written[key] = []
+        return Act(g, a.c0, a.c)
+
+    def _covered(self, key, lo, hi):
+        """Return (fully_written, fully_unwritten, missing ranges) for [lo,hi)."""
+        segs = sorted(self.written[key])
+        missing, cur = [], lo
+        for s, e in segs:
+            if e <= cur:
+                continue
+            if s >= hi:
+                break
+            if s > cur:
+                missing.append((cur, min(s, hi)))
+            cur = max(cur, e)
+            if cur >= hi:
+                break
+        if cur < hi:
+            missing.append((cur, hi))
+        full = not missing
+        none = len(missing) == 1 and missing[0] == (lo, hi)
+        return full, none, missing
+
+    def claim(self, a: Act, eng) -> int:
+        """Called by a backward writer about to write grad_of(a).  Returns the `accumulate` flag
+        and marks the range written; zero-fills gaps when the range is partially written."""
+        key = a.buf.data_ptr()
+        if key not in self.bufs:
+            self.grad_of(a)
+        lo, hi = a.c0, a.c0 + a.c
+        full, none, missing = self._covered(key, lo, hi)
+        if not full:
+            self.written[key].append((lo, hi))
+        if full:
+            return 1
+        if none:
+            return 0
+        g = self.bufs[key]
+        for s, e in missing:                      # rare: partially written -> zero the gaps
+            eng.fill_zero(Act(g, s, e - s))
+        return 1
+
+    def has(self, a: Act) -> bool:
+        key = a.buf.data_ptr()
+        if key not in self.bufs:
+            return False
+        full, _, _ = self._covered(key, a.c0, a.c0 + a.c)
+        return full
+
+
+class Engine:
+    BN_EPS = 1e-5
+    BN_MOMENTUM = 0.1
+
+    def __init__(self, params: ParamStore, dtype=torch.float32, device="cuda"):
+        self.params = params
+        self.dtype = dtype
+        self.device = device
+        self.packer = Packer(params, dtype)
+        self.arena = Arena(device)
+        self.grads = GradBook(self.arena)
+        self.tape: List = []
+        self.bn_train = False          # batch statistics + running-stat updates
+        self.record = False            # build the backward tape
+        self.stats = None              # flat fp32 scratch zeroed once per step
+        self.stats_cursor = 0
+        self.stats_size = 0
+        self._zero = None
+        self.lib = L.lib()
+
+    # ------------------------------------------------------------------ step lifecycle
+    def begin(self, bn_train: bool, record: bool):
+        self.arena.reset()
+        self.grads.reset()
+        self.tape = []
+        self.bn_train, self.record = bn_train, record
+        self.stats_cursor = 0
+        if self.stats is not None:
+            self.stats.zero_()
+
+    def scratch(self, numel) -> torch.Tensor:
+        """fp32 scratch that is zero at step start (BN sums, reductions)."""
+        numel = rup(numel, 4)
+        if self.stats is None or self.stats_cursor + numel > self.stats.numel():
+            # grow: only legal while recording a new configuration (first step)
+            new = torch.zeros(max(2 * (self.stats_cursor + numel), 1 << 16), dtype=torch.float32,
+                              device=self.device)
+            if self.stats is not None:
+                new[:self.stats.numel()].copy_(self.stats)
+                self._stale_stats = True
+            self.stats = new
+        t = self.stats[self.stats_cursor:self.stats_cursor + numel]
+        self.stats_cursor += numel
+        return t
+
+    def f32(self, *shape):
+        return self.arena.alloc(shape, torch.float32)
+
+    def new_act(self, n, h, w, c, ld=None, dtype=None):
+        ld = rup(c, 8) if ld is None else ld
+        return Act(self.arena.alloc((n, h, w, ld), dtype or self.dtype), 0, c)
+
+    def st(self):
+        return L.stream_ptr()
+
+    # ------------------------------------------------------------------ tiny helpers
+    def fill_zero(self, a: Act):
+        L.check(self.lib.isa_axpy(a.d(), a.d(), 0.0, 0, self.st()), "isa_axpy(zero)")
+
+    def copy(self, src: Act, dst: Act):
+        L.check(self.lib.isa_axpy(src.d(), dst.d(), 1.0, 0, self.st()), "isa_axpy(copy)")
+        if self.record and src.needs_grad:
+            def bwd():
+                acc = self.grads.claim(src, self)
+                L.check(self.lib.isa_axpy(self.grads.grad_of(dst).d(), self.grads.grad_of(src).d(), 1.0, acc,
+                                          self.st()), "isa_axpy(bwd)")
+            self.tape.append(bwd)
+
+    # ------------------------------------------------------------------ convolutions
+    def reg_conv(self, wname, taps=1, kmap=None, transposed=False):
+        """Register pack jobs for a conv weight; returns dict of keys."""
+        shape = self.params.shapes[wname]
+        if transposed:                       # ConvTranspose2d [K, Co, 2, 2]
+            k, co = shape[0], shape[1]
+            kphys = len(kmap) if kmap is not None else k
+            kp = rup(kphys, 32)
+            f = self.packer.add(wname, "fwd", 2, co, k, 4, kp, 4 * co, kmap)
+            b = self.packer.add(wname, "dgrad", 3, co, k, 4, rup(co, 32), kphys, kmap)
+            return dict(fwd=f, dgrad=b, kp=kp, kp_d=rup(co, 32), n=4 * co, kphys=kphys)
+        n, k = shape[0], shape[1]
+        kphys = len(kmap) if kmap is not None else k
+        kp = rup(kphys, 32)
+        f = self.packer.add(wname, "fwd", 0, n, k, taps, kp, n, kmap)
+        b = self.packer.add(wname, "dgrad", 1, n, k, taps, rup(n, 32), kphys, kmap)
+        return dict(fwd=f, dgrad=b, kp=kp, kp_d=rup(n, 32), n=n, kphys=kphys)
+
+    def conv(self, x: Act, wname, out: Act, *, taps=1, bias=None, stats=False, kmap=None,
+             transposed=False):
+        """out(raw) = conv(pro(x)).  Returns (out, stats tensor or None)."""
+        reg = self.reg_conv(wname, taps, kmap, transposed)
+        in_mode = L.IN_3X3 if taps == 9 else L.IN_1X1
+        out_mode = L.OUT_SHUFFLE2 if transposed else L.OUT_PLAIN
+        st = self.scratch(2 * out.c) if stats else None
+        job = (x, reg, bias, out, in_mode, out_mode, st)
+        self._launch_conv(*job)
+        if self.record:
+            def bwd():
+                dy = self.grads.grad_of(out)
+                pk = self.packer
+                if transposed:
+                    L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname), None,
+                                                    L.IN_1X1, L.OUT_SHUFFLE2, pk.kmap_ptr(reg["fwd"]),
+                                                    self.params.shapes[wname][0], self.st()), "isa_conv_wgrad")
+                    if bias is not None:
+                        L.check(self.lib.isa_colsum(dy.d(), self.params.gptr(bias), self.st()), "isa_colsum")
+                else:
+                    L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
+                                                    self.params.gptr(bias) if bias else None, in_mode,
+                                                    L.OUT_PLAIN, pk.kmap_ptr(reg["fwd"]),
+                                                    self.params.shapes[wname][1], self.st()), "isa_conv_wgrad")
+                if x.needs_grad:
+                    acc = self.grads.claim(x, self)
+                    dx = self.grads.grad_of(x)
+                    if transposed:
+                        L.check(self.lib.isa_conv_gemm(dy.d(), None, pk.ptr(reg["dgrad"]), reg["kp_d"], None,
+                                                       dx.d(), L.IN_GATHER2, L.OUT_PLAIN, None, acc, self.st()),
+                                "isa_conv_gemm(dgradT)")
+                    else:
+                        L.check(self.lib.isa_conv_gemm(dy.d(), None, pk.ptr(reg["dgrad"]), reg["kp_d"], None,
+                                                       dx.d(), in_mode, L.OUT_PLAIN, None, acc, self.st()),
+                                "isa_conv_gemm(dgrad)")
+            self.tape.append(bwd)
+        return out, st
+
+    def _launch_conv(self, x, reg, bias, out, in_mode, out_mode, st):
+        if self.packer.table is None:
+            self.packer.pack()
+        L.check(self.lib.isa_conv_gemm(x.d(), x.p(), self.packer.ptr(reg["fwd"]), reg["kp"],
+                                       self.params.ptr(bias) if bias else None, out.d(), in_mode, out_mode,
+                                       L.ptr(st), 0, self.st()), "isa_conv_gemm")
+
+    def reg_dw(self, wname, kmap=None):
+        c = self.params.shapes[wname][0]
+        rows = rup(len(kmap) if kmap is not None else c, 8)     # kernel reads rows of rup(C,8)
+        f = self.packer.add(wname, "fwd", 4, c, 1, 9, 0, rows, kmap)
+        b = self.packer.add(wname, "dgrad", 5, c, 1, 9, 0, rows, kmap)
+        return dict(fwd=f, dgrad=b)
+
+    def dwconv(self, x: Act, wname, out: Act, *, bias=None, stats=False, kmap=None):
+        reg = self.reg_dw(wname, kmap)
+        if self.packer.table is None:
+            self.packer.pack()
+        st = self.scratch(2 * out.c) if stats else None
+        L.check(self.lib.isa_dwconv3x3(x.d(), x.p(), self.packer.ptr(reg["fwd"]),
+                                       self.params.ptr(bias) if bias else None, out.d(), L.ptr(st), self.st()),
+                "isa_dwconv3x3")
+        if self.record:
+            def bwd():
+                dy = self.grads.grad_of(out)
+                L.check(self.lib.isa_dwconv3x3_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
+                                                     self.params.gptr(bias) if bias else None,
+                                                     self.params.shapes[wname][0], self.st()),
+                        "isa_dwconv3x3_wgrad")
+                if x.needs_grad:
+                    acc = self.grads.claim(x, self)
+                    L.check(self.lib.isa_dwconv3x3_dgrad(dy.d(), self.packer.ptr(reg["dgrad"]),
+                                                         self.grads.grad_of(x).d(), acc, self.st()),
+                            "isa_dwconv3x3_dgrad")
+            self.tape.append(bwd)
+        return out, st
+
+    # ------------------------------------------------------------------ batch norm
+    def bn(self, raw: Act, stats, pre, act, count=None) -> Act:
+        """Lazy BN(+act): returns a view of `raw` whose prologue applies scale/shift/act.
+        Gradient w.r.t. the lazy tensor is converted in place to the gradient w.r.t. `raw`."""
+        c = raw.c
+        scale, shift, mean, invstd = (self.f32(c) for _ in range(4))
+        count = float(raw.n * raw.h * raw.w) if count is None else float(count)
+        P = self.params
+        train = self.bn_train
+        L.check(self.lib.isa_bn_finalize(L.ptr(stats) if train else None, count, P.ptr(pre + ".weight"),
+                                         P.ptr(pre + ".bias"), P.ptr(pre + ".running_mean"),
+                                         P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
+                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
+                "isa_bn_finalize")
+        if train:
+            P.int_buffers[pre + ".num_batches_tracked"] += 1
+        lazy = raw.with_pro(Pro(scale, shift, act))
+        lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
+                       train=train, raw=raw)
+        if self.record:
+            def bwd():
+                self._bn_backward(lazy, self.grads.grad_of(raw), self.grads.grad_of(raw), None)
+            self.tape.append(bwd)
+        return lazy
+
+    def _bn_backward(self, lazy: Act, dt: Act, dy: Act, bscale):
+        b = lazy.bn
+        P = self.params
+        red = self.scratch(2 * lazy.c) if b["train"] else None
+        if b["train"]:
+            L.check(self.lib.isa_bn_bwd_reduce(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
+                                               L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),
+                                               L.ptr(red), self.st()), "isa_bn_bwd_reduce")
+        L.check(self.lib.isa_bn_bwd_apply(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
+                                          L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),
+                                          P.ptr(b["pre"] + ".weight"), L.ptr(red), b["count"], 1 if b["train"] else 0,
+                                          dy.d(), P.gptr(b["pre"] + ".weight"), P.gptr(b["pre"] + ".bias"),
+                                          self.st()), "isa_bn_bwd_apply")
+
+    def bn_out(self, raw: Act, stats, pre, act, out: Act, res: Optional[Act] = None, bscale=None,
+               count=None) -> Act:
+        """Materialising BN: out = act(BN(raw)) * bscale (+ res)."""
+        c = raw.c
+        scale, shift, mean, invstd = (self.f32(c) for _ in range(4))
+        count = float(raw.n * raw.h * raw.w) if count is None else float(count)
+        P = self.params
+        train = self.bn_train
+        L.check(self.lib.isa_bn_finalize(L.ptr(stats) if train else None, count, P.ptr(pre + ".weight"),
+                                         P.ptr(pre + ".bias"), P.ptr(pre + ".running_mean"),
+                                         P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
+                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
+                "isa_bn_finalize")
+        if train:
+            P.int_buffers[pre + ".num_batches_tracked"] += 1
+        lazy = raw.with_pro(Pro(scale, shift, act, bscale))
+        lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
+                       train=train, raw=raw)
+        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), res.d() if res is not None else None, out.d(),
+                                            self.st()), "isa_affine_act_res")
+        if self.record:
+            def bwd():
+                dout = self.grads.grad_of(out)
+                if res is not None and res.needs_grad:
+                    acc = self.grads.claim(res, self)
+                    L.check(self.lib.isa_axpy(dout.d(), self.grads.grad_of(res).d(), 1.0, acc, self.st()),
+                            "isa_axpy(res)")
+                self.grads.claim(raw, self)       # single consumer: overwrite
+                self._bn_backward(lazy, dout, self.grads.grad_of(raw), bscale)
+            self.tape.append(bwd)
+        return out
+
+    def materialize(self, x: Act, out: Act, res: Optional[Act] = None):
+        """out = pro(x) (+res) for a lazy x that is NOT a BN output (bias+act convs)."""
+        L.check(self.lib.isa_affine_act_res(x.d(), x.p(), res.d() if res is not None else None, out.d(),
+                                            self.st()), "isa_affine_act_res")
+        assert not self.record, "use bn_out / lazy consumers on the training path"
+        return out
+
+    # ------------------------------------------------------------------ pooling
+    def avgpool2(self, x: Act, out: Act):
+        L.check(self.lib.isa_avgpool2(x.d(), out.d(), self.st()), "isa_avgpool2")
+        if self.record and x.needs_grad:
+            def bwd():
+                acc = self.grads.claim(x, self)
+                L.check(self.lib.isa_avgpool2_bwd(self.grads.grad_of(out).d(), self.grads.grad_of(x).d(), acc,
+                                                  self.st()), "isa_avgpool2_bwd")
+            self.tape.append(bwd)
+        return out
+
+    # ------------------------------------------------------------------ backward driver
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []

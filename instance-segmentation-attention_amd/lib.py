@@ -1,0 +1,113 @@
+"""ctypes binding of libisa_kernels.so (include/isa_kernels.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a symbol is absent, importing
+the product path raises.  The CPU oracle under oracle/ is never consulted from here.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libisa_kernels.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3, 4
+IN_1X1, IN_3X3, IN_GATHER2 = 0, 1, 2
+OUT_PLAIN, OUT_SHUFFLE2 = 0, 1
+
+_ERR = {-1: "ISA_EINVAL", -2: "ISA_EALIGN", -3: "ISA_EDTYPE", -4: "ISA_ELAUNCH"}
+
+
+class IsaTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("c", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32)]
+
+
+class IsaPro(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("bscale", C.c_void_p),
+                ("act", C.c_int32)]
+
+
+class IsaPackEntry(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("kind", C.c_int32),
+                ("n", C.c_int32), ("k", C.c_int32), ("taps", C.c_int32), ("kp", C.c_int32),
+                ("kmap_off", C.c_int32), ("rows", C.c_int32)]
+
+
+P_T, P_PRO, VP, I32, F = C.POINTER(IsaTensor), C.POINTER(IsaPro), C.c_void_p, C.c_int32, C.c_float
+
+# name -> argtypes, exactly mirroring include/isa_kernels.h
+SIGNATURES = {
+    "isa_pack_weights": [VP, I32, VP, VP, VP, I32, VP],
+    "isa_conv_gemm": [P_T, P_PRO, VP, I32, VP, P_T, I32, I32, VP, I32, VP],
+    "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP],
+    "isa_colsum": [P_T, VP, VP],
+    "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],
+    "isa_dwconv3x3_dgrad": [P_T, VP, P_T, I32, VP],
+    "isa_dwconv3x3_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, VP],
+    "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
+    "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
+    "isa_bn_bwd_apply": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP, F, I32, P_T, VP, VP, VP],
+    "isa_affine_act_res": [P_T, P_PRO, P_T, P_T, VP],
+    "isa_axpy": [P_T, P_T, F, I32, VP],
+    "isa_avgpool2": [P_T, P_T, VP],
+    "isa_avgpool2_bwd": [P_T, P_T, I32, VP],
+    "isa_pool_f": [P_T, P_T, I32, I32, VP],
+    "isa_avgpool3": [P_T, P_T, P_T, VP],
+    "isa_chan_mean": [P_T, P_PRO, VP, VP],
+    "isa_se_fc": [VP, VP, VP, VP, VP, I32, I32, I32, VP, VP, VP],
+    "isa_chan_argmax": [P_T, P_T, VP],
+    "isa_nchw_to_nhwc": [VP, I32, P_T, VP],
+    "isa_nhwc_to_nchw": [P_T, VP, VP],
+}
+
+
+class IsaError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "HIP kernel library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C instance-segmentation-attention_amd/csrc`. There is no CPU fallback."
+            % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise IsaError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise IsaError("unsupported activation dtype %s" % dt)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

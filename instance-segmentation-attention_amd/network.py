@@ -1,0 +1,132 @@
+"""The ReSeg hot path composed from engine ops (reference: code/lib/archs/reseg.py:106-130).
+
+Buffer plan (NHWC, one buffer per pyramid level, zero-copy concats — see DESIGN.md §layout):
+  L256 buf[.,64]  = [ x1 (inc out, 32) | up4 convT out (32) ]      -> up4 reads the whole row
+  L128 buf[.,128] = [ conv(32) | mean2x2(32) | up3 convT (64) ]    x2 = first 64
+  L64  buf[.,256] = [ conv(64) | mean(64)   | up2 convT (128) ]    x3 = first 128
+  L32  buf[.,512] = [ conv(128)| mean(128)  | up1 convT (256) ]    x4 = first 256
+  L16  buf[.,512] = [ conv(256)| mean(256) ]                       x5
+so torch.cat in unet_parts.py:60,91 costs nothing: producers write into channel slices.
+"""
+import torch
+
+from . import lib as L
+from .engine import Act, Engine, Pro, rup
+
+
+class Network:
+    def __init__(self, eng: Engine, use_instance_seg=True):
+        self.E = eng
+        self.use_instance_seg = use_instance_seg
+
+    # ------------------------------------------------------------------ blocks
+    def block_v1(self, x: Act, pre: str, out: Act):
+        """InvertedV1Residual (MobileNetDenseASPP.py:68-93): dw3x3-BN-ReLU6-pw-BN (+x)."""
+        E = self.E
+        cin = x.c
+        cout = E.params.shapes[pre + ".conv.3.weight"][0]
+        y1 = E.new_act(x.n, x.h, x.w, cin)
+        _, s1 = E.dwconv(x, pre + ".conv.0.weight", y1, stats=True)
+        y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
+        y2 = E.new_act(x.n, x.h, x.w, cout)
+        _, s2 = E.conv(y1, pre + ".conv.3.weight", y2, stats=True)
+        return E.bn_out(y2, s2, pre + ".conv.4", L.ACT_NONE, out, res=x if cin == cout else None)
+
+    def block_ir(self, x: Act, pre: str, out: Act, bscale=None, extra_res: Act = None):
+        """InvertedResidual (MobileNetDenseASPP.py:96-123): pw-BN-ReLU6-dw-BN-ReLU6-pw-BN (+x).
+        `bscale` folds a following Dropout2d into the materialising pass."""
+        E = self.E
+        cin = x.c
+        chid = E.params.shapes[pre + ".conv.0.weight"][0]
+        cout = E.params.shapes[pre + ".conv.6.weight"][0]
+        y1 = E.new_act(x.n, x.h, x.w, chid)
+        _, s1 = E.conv(x, pre + ".conv.0.weight", y1, stats=True)
+        y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
+        y2 = E.new_act(x.n, x.h, x.w, chid)
+        _, s2 = E.dwconv(y1, pre + ".conv.3.weight", y2, stats=True)
+        y2 = E.bn(y2, s2, pre + ".conv.4", L.ACT_RELU6)
+        y3 = E.new_act(x.n, x.h, x.w, cout)
+        _, s3 = E.conv(y2, pre + ".conv.6.weight", y3, stats=True)
+        return E.bn_out(y3, s3, pre + ".conv.7", L.ACT_NONE, out, res=x if cin == cout else None,
+                        bscale=bscale)
+
+    def double_v1(self, x: Act, pre: str, out: Act):
+        E = self.E
+        cmid = E.params.shapes[pre + ".conv.down_conv_0.conv.3.weight"][0]
+        mid = E.new_act(x.n, x.h, x.w, cmid)
+        self.block_v1(x, pre + ".conv.down_conv_0", mid)
+        return self.block_v1(mid, pre + ".conv.down_conv_1", out)
+
+    # ------------------------------------------------------------------ backbone
+    def unet(self, x_in: Act):
+        """UNet.forward (unet_model.py:23-36).  x_in: [n,h,w,21] view (ld 24)."""
+        E = self.E
+        n, h, w = x_in.n, x_in.h, x_in.w
+        widths = [(64, 32), (128, 64), (256, 128), (512, 256), (512, 512)]   # (buffer ld, x_k width)
+        bufs = []
+        for lvl, (ld, _) in enumerate(widths):
+            bufs.append(E.new_act(n, h >> lvl, w >> lvl, ld, ld=ld))
+        x1 = bufs[0].slice(0, 32)
+        self.double_v1(x_in, "base.inc.conv", x1)
+        feats = [x1]
+        cur = x1
+        for lvl in range(1, 5):
+            cw = widths[lvl][1] // 2                       # conv half / pooled half
+            pooled = bufs[lvl].slice(cw, cw)
+            E.avgpool2(cur, pooled)
+            self.double_v1(pooled, "base.down%d.mpconv" % lvl, bufs[lvl].slice(0, cw))
+            cur = bufs[lvl].slice(0, 2 * cw)
+            feats.append(cur)
+        y = feats[4]
+        for i, lvl in enumerate((3, 2, 1, 0)):
+            pre = "base.up%d" % (i + 1)
+            skip_w = widths[lvl][1]
+            co = E.params.shapes[pre + ".up.weight"][1]
+            up_dst = bufs[lvl].slice(skip_w, co)
+            E.conv(y, pre + ".up.weight", up_dst, bias=pre + ".up.bias", transposed=True)
+            cat = bufs[lvl].slice(0, skip_w + co)
+            out = E.new_act(n, h >> lvl, w >> lvl, co)
+            y = self.double_v1(cat, pre + ".conv", out)
+        return y, feats
+
+    # ------------------------------------------------------------------ heads
+    def sem_head(self, x_dec: Act):
+        """channelAttend (utils.py:402-420) + sem_seg_output (reseg.py:73-75,115-116)."""
+        E = self.E
+        P = E.params
+        n, c = x_dec.n, x_dec.c
+        mean = E.scratch(n * c)
+        L.check(E.lib.isa_chan_mean(x_dec.d(), None, L.ptr(mean), E.st()), "isa_chan_mean")
+        hid, gate = E.f32(n * 16), E.f32(n * c)
+        L.check(E.lib.isa_se_fc(L.ptr(mean), P.ptr("channelAttend.fc.0.weight"), P.ptr("channelAttend.fc.0.bias"),
+                                P.ptr("channelAttend.fc.2.weight"), P.ptr("channelAttend.fc.2.bias"), n, c, 16,
+                                L.ptr(hid), L.ptr(gate), E.st()), "isa_se_fc")
+        gated = x_dec.with_pro(Pro(bscale=gate))
+        sem = E.new_act(n, x_dec.h, x_dec.w, 2)
+        E.conv(gated, "sem_seg_output.weight", sem, bias="sem_seg_output.bias")
+        self._se_ctx = dict(mean=mean, hid=hid, gate=gate, x=x_dec, gated=gated)
+        return sem
+
+    def argmax_map(self, logits: Act):
+        E = self.E
+        out = E.new_act(logits.n, logits.h, logits.w, 1)
+        L.check(E.lib.isa_chan_argmax(logits.d(), out.d(), E.st()), "isa_chan_argmax")
+        return out
+
+    # ------------------------------------------------------------------ boundary
+    def to_nhwc(self, x: torch.Tensor, c_pad=None) -> Act:
+        """NCHW fp32 (reference layout) -> NHWC activation view."""
+        E = self.E
+        n, c, h, w = x.shape
+        x = x.contiguous()
+        dst = E.new_act(n, h, w, c, ld=rup(c, 8))
+        dst.needs_grad = False
+        self._keep = x
+        L.check(E.lib.isa_nchw_to_nhwc(L.ptr(x), c, dst.d(), E.st()), "isa_nchw_to_nhwc")
+        return dst
+
+    def to_nchw(self, a: Act) -> torch.Tensor:
+        E = self.E
+        out = torch.empty((a.n, a.c, a.h, a.w), dtype=torch.float32, device=a.buf.device)
+        L.check(E.lib.isa_nhwc_to_nchw(a.d(), L.ptr(out), E.st()), "isa_nhwc_to_nchw")
+        return out

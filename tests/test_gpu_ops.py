@@ -1,0 +1,245 @@
+"""Op-level parity: every HIP entry point against a torch fp32 reference of the same op.
+
+Run on the GPU box: python -m pytest tests -m gpu.  All calls go through the C-ABI library via
+the engine wrappers; the torch functions here are only the checkers.
+Tolerances: fp32 storage 2e-5 relative to max|ref| (exact-f32 MFMA, different summation order);
+bf16 storage 2e-2 (one bf16 rounding of inputs and of the stored result, fp32 accumulation).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import isa_amd  # noqa: F401
+    from isa_amd import lib as L
+    from isa_amd.engine import Act, Engine, ParamStore, Pro
+    return L, Act, Engine, ParamStore, Pro
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def to_act(Act, t_nchw, dtype, ld=None, c0=0):
+    """NCHW cpu tensor -> Act on GPU (optionally inside a wider buffer at channel offset c0)."""
+    n, c, h, w = t_nchw.shape
+    ld = ld or (c + 7) // 8 * 8
+    buf = torch.full((n, h, w, ld), 7.0, dtype=dtype, device="cuda")
+    buf[..., c0:c0 + c] = t_nchw.permute(0, 2, 3, 1).to(dtype).cuda()
+    return Act(buf, c0, c)
+
+
+def q(t, dtype):
+    """Quantise a reference input the way storage does."""
+    return t.to(dtype).float()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_engine(Engine, ParamStore, schema, tensors, dtype):
+    ps = ParamStore(schema, "cuda")
+    ps.load_state_dict(tensors)
+    eng = Engine(ps, dtype)
+    eng.begin(bn_train=True, record=False)
+    return eng
+
+
+def rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,hw,batch", [(32, 32, 16, 2), (21, 32, 8, 1), (64, 246, 8, 2),
+                                               (512, 1024, 4, 2), (256, 120, 8, 1), (24, 12, 8, 2),
+                                               (32, 2, 16, 2)])
+def test_conv1x1(dtype, cin, cout, hw, batch):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    w = rand(cout, cin, 1, 1, seed=1, scale=cin ** -0.5)
+    b = rand(cout, seed=2)
+    x = rand(batch, cin, hw, hw + 3, seed=3)
+    eng = make_engine(Engine, ParamStore, [("w", w.shape), ("b", b.shape)], dict(w=w, b=b), dtype)
+    xa = to_act(Act, x, dtype)
+    ya = eng.new_act(batch, hw, hw + 3, cout, ld=(cout + 15) // 8 * 8)
+    ya.buf.fill_(5.0)
+    _, st = eng.conv(xa, "w", ya, bias="b", stats=True)
+    torch.cuda.synchronize()
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b)
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+    # untouched padding channels
+    assert float((ya.buf[..., cout:].float() - 5.0).abs().max()) == 0.0
+    # fused BN statistics
+    s = st.cpu()
+    assert rel(s[:cout], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    assert rel(s[cout:2 * cout], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1x1_lazy_prologue(dtype):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    cin, cout, hw, batch = 48, 24, 8, 2
+    w = rand(cout, cin, 1, 1, seed=1, scale=cin ** -0.5)
+    x = rand(batch, cin, hw, hw, seed=3, scale=3.0)
+    sc, sh = rand(cin, seed=4).abs() + 0.5, rand(cin, seed=5)
+    bs = (rand(batch, cin, seed=6) > 0).float() * 2.0
+    eng = make_engine(Engine, ParamStore, [("w", w.shape)], dict(w=w), dtype)
+    xa = to_act(Act, x, dtype).with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6, bs.cuda().contiguous()))
+    ya = eng.new_act(batch, hw, hw, cout)
+    eng.conv(xa, "w", ya)
+    torch.cuda.synchronize()
+    xt = torch.clamp(q(x, dtype) * sc[None, :, None, None] + sh[None, :, None, None], 0, 6) * bs[:, :, None, None]
+    ref = F.conv2d(q(xt, dtype) if dtype == torch.bfloat16 else xt, q(w, dtype))
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,hw", [(32, 16, 12), (16, 2, 16), (12, 1, 8), (256, 128, 4)])
+def test_conv3x3_dense(dtype, cin, cout, hw):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    batch = 2
+    w = rand(cout, cin, 3, 3, seed=1, scale=(9 * cin) ** -0.5)
+    b = rand(cout, seed=2)
+    x = rand(batch, cin, hw, hw + 1, seed=3)
+    eng = make_engine(Engine, ParamStore, [("w", w.shape), ("b", b.shape)], dict(w=w, b=b), dtype)
+    xa = to_act(Act, x, dtype)
+    ya = eng.new_act(batch, hw, hw + 1, cout)
+    eng.conv(xa, "w", ya, taps=9, bias="b")
+    torch.cuda.synchronize()
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,hw", [(64, 32, 8), (512, 256, 4)])
+def test_conv_transpose(dtype, cin, cout, hw):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    batch = 2
+    w = rand(cin, cout, 2, 2, seed=1, scale=cin ** -0.5)
+    b = rand(cout, seed=2)
+    x = rand(batch, cin, hw, hw, seed=3)
+    eng = make_engine(Engine, ParamStore, [("w", w.shape), ("b", b.shape)], dict(w=w, b=b), dtype)
+    xa = to_act(Act, x, dtype)
+    big = eng.new_act(batch, 2 * hw, 2 * hw, 2 * cout, ld=2 * cout)
+    big.buf.fill_(3.0)
+    ya = big.slice(cout, cout)                      # write into the second half of a concat buffer
+    eng.conv(xa, "w", ya, bias="b", transposed=True)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(q(x, dtype), q(w, dtype), b, stride=2)
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+    assert float((big.buf[..., :cout].float() - 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,h,w", [(32, 16, 16), (21, 9, 20), (48, 8, 8), (1024, 4, 4)])
+def test_dwconv(dtype, c, h, w):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    batch = 2
+    wt = rand(c, 1, 3, 3, seed=1, scale=1 / 3.0)
+    b = rand(c, seed=2)
+    x = rand(batch, c, h, w, seed=3)
+    sc, sh = rand(c, seed=4).abs() + 0.5, rand(c, seed=5)
+    eng = make_engine(Engine, ParamStore, [("w", wt.shape), ("b", b.shape)], dict(w=wt, b=b), dtype)
+    xa = to_act(Act, x, dtype).with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6))
+    ya = eng.new_act(batch, h, w, c)
+    _, st = eng.dwconv(xa, "w", ya, bias="b", stats=True)
+    torch.cuda.synchronize()
+    xt = torch.clamp(q(x, dtype) * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
+    ref = F.conv2d(xt, q(wt, dtype), b, padding=1, groups=c)
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+    s = st.cpu()
+    assert rel(s[:c], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    assert rel(s[c:2 * c], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_finalize_and_materialize(dtype):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    c, batch, hw = 24, 2, 8
+    x = rand(batch, c, hw, hw, seed=3, scale=2.0) + 0.5
+    res = rand(batch, c, hw, hw, seed=4)
+    g, b = rand(c, seed=5).abs() + 0.5, rand(c, seed=6)
+    rm, rv = rand(c, seed=7) * 0.1, rand(c, seed=8).abs() + 0.5
+    schema = [("bn.weight", (c,)), ("bn.bias", (c,)), ("bn.running_mean", (c,)), ("bn.running_var", (c,)),
+              ("bn.num_batches_tracked", ())]
+    for train in (True, False):
+        eng = make_engine(Engine, ParamStore, schema,
+                          {"bn.weight": g, "bn.bias": b, "bn.running_mean": rm, "bn.running_var": rv}, dtype)
+        eng.bn_train = train
+        xa = to_act(Act, x, dtype)
+        xq = q(x, dtype)
+        st = torch.cat([xq.sum((0, 2, 3)), (xq * xq).sum((0, 2, 3))]).cuda()
+        out = eng.new_act(batch, hw, hw, c)
+        eng.bn_out(xa, st, "bn", L.ACT_RELU6, out, res=to_act(Act, res, dtype))
+        torch.cuda.synchronize()
+        ref = F.batch_norm(xq, rm.clone(), rv.clone(), g, b, training=train, momentum=0.1, eps=1e-5)
+        ref = torch.clamp(ref, 0, 6) + q(res, dtype)
+        assert rel(out.nchw(), ref) < max(TOL[dtype], 1e-4)
+        if train:
+            rm2, rv2 = rm.clone(), rv.clone()
+            F.batch_norm(xq, rm2, rv2, g, b, training=True, momentum=0.1, eps=1e-5)
+            assert rel(eng.params.view("bn.running_mean"), rm2) < 1e-4
+            assert rel(eng.params.view("bn.running_var"), rv2) < 1e-4
+            assert eng.params.int_buffers["bn.num_batches_tracked"] == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_avgpool2_and_layout(dtype):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    from isa_amd.network import Network
+    x = rand(2, 21, 8, 12, seed=1)
+    eng = make_engine(Engine, ParamStore, [("dummy", (4,))], {}, dtype)
+    net = Network(eng)
+    xa = net.to_nhwc(x.cuda())
+    torch.cuda.synchronize()
+    assert xa.ld == 24 and rel(xa.nchw(), q(x, dtype)) < 1e-7
+    back = net.to_nchw(xa)
+    assert rel(back, q(x, dtype)) < 1e-7
+    x2 = rand(2, 32, 8, 12, seed=2)
+    a = to_act(Act, x2, dtype)
+    out = eng.new_act(2, 4, 6, 32)
+    eng.avgpool2(a, out)
+    torch.cuda.synchronize()
+    assert rel(out.nchw(), F.avg_pool2d(q(x2, dtype), 2)) < TOL[dtype]
+
+
+def test_se_gate_and_argmax():
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    dtype = torch.float32
+    n, c, hw = 2, 32, 8
+    x = rand(n, c, hw, hw, seed=1)
+    w1, b1, w2, b2 = rand(16, c, seed=2) * 0.3, rand(16, seed=3), rand(c, 16, seed=4) * 0.3, rand(c, seed=5)
+    eng = make_engine(Engine, ParamStore, [("d", (4,))], {}, dtype)
+    xa = to_act(Act, x, dtype)
+    mean = torch.zeros(n * c, device="cuda")
+    L.check(eng.lib.isa_chan_mean(xa.d(), None, L.ptr(mean), eng.st()), "mean")
+    gate, hid = torch.empty(n * c, device="cuda"), torch.empty(n * 16, device="cuda")
+    d = [t.cuda().contiguous() for t in (w1, b1, w2, b2)]
+    L.check(eng.lib.isa_se_fc(L.ptr(mean), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]), n, c, 16,
+                              L.ptr(hid), L.ptr(gate), eng.st()), "se")
+    torch.cuda.synchronize()
+    m = x.mean((2, 3))
+    ref = torch.sigmoid(F.linear(F.relu(F.linear(m, w1, b1)), w2, b2))
+    assert rel(mean.view(n, c), m) < 1e-5
+    assert rel(gate.view(n, c), ref) < 1e-5
+    lg = rand(2, 2, 8, 8, seed=9)
+    la = to_act(Act, lg, dtype)
+    out = eng.new_act(2, 8, 8, 1)
+    L.check(eng.lib.isa_chan_argmax(la.d(), out.d(), eng.st()), "argmax")
+    torch.cuda.synchronize()
+    assert torch.equal(out.nchw().cpu()[:, 0], lg.argmax(1).float())
