@@ -133,8 +133,10 @@ int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const float* sca
 
 /* ---- materialise a lazy tensor: out = pro(x) (+ res)  (residual adds of Inverted*Residual,
  * F.dropout2d, torch.cat placement) and its backward pieces ----------------------------------- */
+/* out = (pro(x) (+res) (+res2)) * oscale[n,c]   (oscale: F.dropout2d after a residual sum) */
 int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
-                       const isa_tensor* out, void* stream);
+                       const isa_tensor* res2, const float* oscale, const isa_tensor* out,
+                       void* stream);
 /* dst (+)= src  (NHWC views; gradient fan-in of residual/skip connections) */
 int isa_axpy(const isa_tensor* src, const isa_tensor* dst, float alpha, int32_t accumulate,
              void* stream);
@@ -157,6 +159,42 @@ int isa_se_fc(const float* mean, const float* w1, const float* b1, const float* 
               void* stream);
 /* argmax over channels -> float map in {0..c-1} (first max wins, torch.argmax) */
 int isa_chan_argmax(const isa_tensor* x, const isa_tensor* y, void* stream);
+
+/* ---- attention mask head (utils.py:457-663, attenet2.py:304-347) ---------------------------------
+ * Single-channel maps (masks, scores, probabilities, targets) are fp32 [n, h*w] arrays.
+ * SpatialAttentionLayer (utils.py:484-523), four steps: */
+int isa_mask_dot(const isa_tensor* x, const float* m, const float* w, const float* bias,
+                 float* dot /*zeroed*/, float* chansum /*[n,c] zeroed*/, void* stream);
+int isa_sp_softmax(const float* dot, const float* m, const float* chansum, const float* lh,
+                   const float* fcw, const float* fcb, int32_t n, int32_t c, int64_t L,
+                   float* beta, float* rowstat /*[n,4]: max,sumexp,count,h_t*/, void* stream);
+int isa_scaled_stats(const isa_tensor* x, const float* beta, float* stats /*[2c] zeroed*/, void* stream);
+int isa_sp_apply(const isa_tensor* x, const float* beta, const float* m, const float* scale,
+                 const float* shift, const isa_tensor* out, void* stream);
+/* maskBN (utils.py:568-591) on the 1-channel score map, fused with AvgPool3x3 * sem (utils.py:645) */
+int isa_maskbn_stats(const isa_tensor* e, const float* m, const float* mean_in, float* out, void* stream);
+int isa_maskbn_finalize(const float* am, const float* v, int32_t n, int32_t stage, float* mean_var,
+                        float* running_mean, float* running_var, float f, int32_t train, void* stream);
+int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, const float* mean_var, const float* w,
+                          const float* b, float eps, float* merge, void* stream);
+/* HardAttentionLayer softmax for the selected instance of each image (utils.py:648-655 + the
+ * gather of attenet2.py:342-343): alpha[b,:] = softmax over pixels of ins[b, idx[b]] */
+int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
+                    int64_t L, float* alpha, float* rowstat /*[n,2]*/, void* stream);
+/* DecoderLayer.sample eval branch (attenet2.py:324): first argmax per row, on device */
+int isa_row_argmax(const float* a, int32_t n, int64_t L, int32_t* out, void* stream);
+/* UpDecoderLayer.resize (utils.py:841-846): f x f max-pool of the instance plane / of an fp32 map */
+int isa_pool_target(const int64_t* ins, const int32_t* idx, const float* src, int32_t nobj, int32_t n,
+                    int32_t H, int32_t W, int32_t f, float* out, void* stream);
+/* mask_all + conPosition channels (utils.py:1027-1045,1085) written into a concat slice */
+int isa_concat_aux(const isa_tensor* dst, const float* mask_all, const int32_t* s_t, int32_t W_full,
+                   int32_t f, int32_t nb, void* stream);
+/* UpAttenLayer.Mask (utils.py:1047-1056): out = up * softmax2(bilinear_x2(pred))[1] */
+int isa_gate(const isa_tensor* up, const isa_tensor* pred, const isa_tensor* out, float* gmap, void* stream);
+/* per-image sums for dice / focal / CE of a 2-class prediction (dice.py:10-51, multi_loss.py:27-42):
+ * sums[b][0..6] = {sum p1*t, sum p1, sum t, sum focal, sum ce, sum p1^2, count}; stride 8 floats */
+int isa_mask_loss_sums(const isa_tensor* pred, const float* target, const int64_t* onehot, float* sums,
+                       void* stream);
 
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);

@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
     }
 }
 
-// out = pro(x) (+ res)
-struct MatParams { View x, res, out; ProDev pro; long pixels; int cg; int has_res; };
+// out = (pro(x) (+ res) (+ res2)) * oscale[b,c]
+struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; };
 template <typename T>
 __global__ __launch_bounds__(256) void materialize_kernel(MatParams p) {
     const long items = p.pixels * p.cg;
@@ -201,6 +201,16 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatParams p) {
             load8g<T>(reinterpret_cast<const T*>(p.res.data) + pix * p.res.ld + c0, rr, nv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+        if (p.has_res2) {
+            float rr[8];
+            load8g<T>(reinterpret_cast<const T*>(p.res2.data) + pix * p.res2.ld + c0, rr, nv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+        if (p.oscale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= p.oscale[(long)b * C + min(c0 + j, C - 1)];
         }
         store8g<T>(reinterpret_cast<T*>(p.out.data) + pix * p.out.ld + c0, v, nv);
     }
@@ -494,12 +504,16 @@ extern "C" int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const
 }
 
 extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
+                                  const isa_tensor* res2, const float* oscale,
                                   const isa_tensor* out, void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !same_shape(x, out)) return ISA_EINVAL;
     if (res && (!tensor_ok(res, 8) || !same_shape(res, x))) return ISA_EINVAL;
+    if (res2 && (!tensor_ok(res2, 8) || !same_shape(res2, x))) return ISA_EINVAL;
     MatParams p{};
     p.x = mkview(x); p.out = mkview(out); p.pro = make_pro(pro); p.has_res = res != nullptr;
+    p.has_res2 = res2 != nullptr; p.oscale = oscale;
     if (res) p.res = mkview(res);
+    if (res2) p.res2 = mkview(res2);
     p.pixels = (long)x->n * x->h * x->w; p.cg = (x->c + 7) / 8;
     const int grid = grid_cap(cdiv(p.pixels * p.cg, 256));
     DISPATCH_T(x->dtype,

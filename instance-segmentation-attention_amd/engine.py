@@ -505,8 +505,8 @@ class Engine:
                                           self.st()), "isa_bn_bwd_apply")
 
     def bn_out(self, raw: Act, stats, pre, act, out: Act, res: Optional[Act] = None, bscale=None,
-               count=None) -> Act:
-        """Materialising BN: out = act(BN(raw)) * bscale (+ res)."""
+               count=None, res2: Optional[Act] = None, oscale=None) -> Act:
+        """Materialising BN: out = (act(BN(raw)) * bscale (+ res) (+ res2)) * oscale."""
         c = raw.c
         scale, shift, mean, invstd = (self.f32(c) for _ in range(4))
         count = float(raw.n * raw.h * raw.w) if count is None else float(count)
@@ -522,7 +522,8 @@ class Engine:
         lazy = raw.with_pro(Pro(scale, shift, act, bscale))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
-        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), res.d() if res is not None else None, out.d(),
+        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), res.d() if res is not None else None,
+                                            res2.d() if res2 is not None else None, L.ptr(oscale), out.d(),
                                             self.st()), "isa_affine_act_res")
         if self.record:
             def bwd():
@@ -538,8 +539,8 @@ class Engine:
 
     def materialize(self, x: Act, out: Act, res: Optional[Act] = None):
         """out = pro(x) (+res) for a lazy x that is NOT a BN output (bias+act convs)."""
-        L.check(self.lib.isa_affine_act_res(x.d(), x.p(), res.d() if res is not None else None, out.d(),
-                                            self.st()), "isa_affine_act_res")
+        L.check(self.lib.isa_affine_act_res(x.d(), x.p(), res.d() if res is not None else None, None, None,
+                                            out.d(), self.st()), "isa_affine_act_res")
         assert not self.record, "use bn_out / lazy consumers on the training path"
         return out
 

@@ -1,0 +1,297 @@
+"""Attention mask-prediction head composed from engine ops.
+
+Reference: reseg.py:78-102,122-126 (stems), attenet2.py:357-407 (DecoderLayer.forward driver),
+attenet2.py:443-473 (AttenDecoder), utils.py:457-663 (attention layers), utils.py:816-1112
+(UpDecoderLayer / UpAttenLayer / L0Layer), attenet2.py:86-141,204-290 (losses).
+
+What changes vs. the reference's control flow (same results, MI355X-first):
+  * nothing leaves the device inside the iteration loop: the reference copies alpha to the CPU,
+    samples there and rebuilds Python int lists (attenet2.py:306-332); here argmax / injected samples
+    stay in a device int32 vector that the position-code kernel reads;
+  * HardAttentionLayer's [B,32,H,W] softmax (utils.py:648-655) is evaluated only for the instance
+    each iteration actually selects (B rows, not 32*B);
+  * concat order inside the decoder is [gated_up | cross | mask_all | position] so every slice
+    starts 16-byte aligned; conv1's weight columns are permuted to match when packed.
+"""
+import math
+
+import torch
+
+from . import lib as L
+from .engine import Act, Engine, Pro
+
+SKIP_CH = (512, 256, 128, 64, 32)
+OUT_CH = (256, 128, 64, 32, 32)
+FACTORS = (16, 8, 4, 2, 1)
+PYRAMID_W = (16.0, 8.0, 4.0, 2.0, 1.0)     # config.py:51
+CE_WEIGHT = 10.0                            # config.py:17
+LAMBDA_L, LAMBDA_R = 0.5, 2.0               # config.py:45-46
+MAX_ITER = 2                                # config.py:56
+DROP_RATE = 0.5                             # config.py:64
+
+
+class InstanceHead:
+    def __init__(self, net):
+        self.net = net
+        self.E: Engine = net.E
+        self.drop_rate = DROP_RATE
+        self.baseline = None            # device scalar (REINFORCE EMA baseline, attenet2.py:47,266)
+
+    # ------------------------------------------------------------------ stems (reseg.py:78-102)
+    def stems(self, x_dec: Act) -> Act:
+        E, net = self.E, self.net
+        n, h, w = x_dec.n, x_dec.h, x_dec.w
+        p1, p2 = "ins_seg_output_1", "ins_seg_output_2"
+        y = E.new_act(n, h, w, 32)
+        _, s = E.dwconv(x_dec, p1 + ".0.weight", y, bias=p1 + ".0.bias", stats=True)
+        y = E.bn(y, s, p1 + ".1", L.ACT_RELU6)
+        z = E.new_act(n, h, w, 24)
+        _, s = E.conv(y, p1 + ".3.weight", z, bias=p1 + ".3.bias", stats=True)
+        e1 = E.new_act(n, h, w, 24)
+        E.bn_out(z, s, p1 + ".4", L.ACT_RELU6, e1)
+        y = E.new_act(n, h, w, 48)
+        _, s = E.conv(e1, p2 + ".0.weight", y, bias=p2 + ".0.bias", stats=True)
+        y = E.bn(y, s, p2 + ".1", L.ACT_RELU6)
+        z = E.new_act(n, h, w, 48)
+        _, s = E.dwconv(y, p2 + ".3.weight", z, bias=p2 + ".3.bias", stats=True)
+        z = E.bn(z, s, p2 + ".4", L.ACT_RELU6)
+        y = E.new_act(n, h, w, 24)
+        _, s = E.conv(z, p2 + ".6.weight", y, bias=p2 + ".6.bias", stats=True)
+        x_enc = E.new_act(n, h, w, 24)
+        return E.bn_out(y, s, p2 + ".7", L.ACT_NONE, x_enc, res=e1)
+
+    # ------------------------------------------------------------------ a7 SpatialAttentionLayer
+    def spatial_attention(self, x: Act, sem: torch.Tensor) -> Act:
+        E, P = self.E, self.E.params
+        n, c, Lp = x.n, x.c, x.h * x.w
+        pre = "decoder.s_sp"
+        dot, chansum = E.scratch(n * Lp), E.scratch(n * c)
+        L.check(E.lib.isa_mask_dot(x.d(), L.ptr(sem), P.ptr(pre + ".l_v.weight"), P.ptr(pre + ".l_v.bias"),
+                                   L.ptr(dot), L.ptr(chansum), E.st()), "isa_mask_dot")
+        beta, rowstat = E.f32(n * Lp), E.f32(n * 4)
+        L.check(E.lib.isa_sp_softmax(L.ptr(dot), L.ptr(sem), L.ptr(chansum), P.ptr(pre + ".l_h.weight"),
+                                     P.ptr(pre + ".spatial_fc.1.weight"), P.ptr(pre + ".spatial_fc.1.bias"),
+                                     n, c, Lp, L.ptr(beta), L.ptr(rowstat), E.st()), "isa_sp_softmax")
+        scale, shift, mean, invstd = (E.f32(c) for _ in range(4))
+        stats = E.scratch(2 * c)
+        if E.bn_train:
+            L.check(E.lib.isa_scaled_stats(x.d(), L.ptr(beta), L.ptr(stats), E.st()), "isa_scaled_stats")
+            P.int_buffers[pre + ".bn.num_batches_tracked"] += 1
+        L.check(E.lib.isa_bn_finalize(L.ptr(stats) if E.bn_train else None, float(n * Lp), P.ptr(pre + ".bn.weight"),
+                                      P.ptr(pre + ".bn.bias"), P.ptr(pre + ".bn.running_mean"),
+                                      P.ptr(pre + ".bn.running_var"), E.BN_MOMENTUM, E.BN_EPS, L.ptr(scale),
+                                      L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, E.st()), "isa_bn_finalize")
+        out = E.new_act(n, x.h, x.w, c)
+        L.check(E.lib.isa_sp_apply(x.d(), L.ptr(beta), L.ptr(sem), L.ptr(scale), L.ptr(shift), out.d(), E.st()),
+                "isa_sp_apply")
+        self._sp_ctx = dict(x=x, dot=dot, chansum=chansum, beta=beta, rowstat=rowstat, scale=scale, shift=shift,
+                            mean=mean, invstd=invstd, out=out)
+        return out
+
+    # ------------------------------------------------------------------ a8/a9 HardAttentionLayer front
+    def hard_attention_scores(self, s: Act, sem: torch.Tensor) -> torch.Tensor:
+        """Returns pro_merge as an fp32 [n, h*w] map."""
+        E, P = self.E, self.E.params
+        n, h, w = s.n, s.h, s.w
+        pre = "decoder.attend"
+        sp = E.new_act(n, h, w, s.c)
+        L.check(E.lib.isa_avgpool3(s.d(), None, sp.d(), E.st()), "isa_avgpool3")
+        e1 = E.new_act(n, h, w, 12)
+        E.conv(sp, pre + ".l1.weight", e1, bias=pre + ".l1.bias")
+        e2 = E.new_act(n, h, w, 1)
+        E.conv(e1.with_pro(Pro(act=L.ACT_TANH)), pre + ".attend_fc.1.weight", e2, taps=9,
+               bias=pre + ".attend_fc.1.bias")
+        am, v, mean_var = E.f32(2 * n), E.f32(n), E.f32(2)
+        train = 1 if E.bn_train else 0
+        rm, rv = P.ptr(pre + ".bn.running_mean"), P.ptr(pre + ".bn.running_var")
+        if train:
+            L.check(E.lib.isa_maskbn_stats(e2.d(), L.ptr(sem), None, L.ptr(am), E.st()), "isa_maskbn_stats")
+        L.check(E.lib.isa_maskbn_finalize(L.ptr(am), L.ptr(v), n, 0, L.ptr(mean_var), rm, rv, E.BN_MOMENTUM, train,
+                                          E.st()), "isa_maskbn_finalize")
+        if train:
+            L.check(E.lib.isa_maskbn_stats(e2.d(), L.ptr(sem), L.ptr(mean_var), L.ptr(v), E.st()), "isa_maskbn_stats")
+            L.check(E.lib.isa_maskbn_finalize(L.ptr(am), L.ptr(v), n, 1, L.ptr(mean_var), rm, rv, E.BN_MOMENTUM, 1,
+                                              E.st()), "isa_maskbn_finalize")
+            P.int_buffers[pre + ".bn.num_batches_tracked"] += 1
+        merge = E.f32(n * h * w)
+        L.check(E.lib.isa_maskbn_apply_pool(e2.d(), L.ptr(sem), L.ptr(mean_var), P.ptr(pre + ".bn.weight"),
+                                            P.ptr(pre + ".bn.bias"), E.BN_EPS, L.ptr(merge), E.st()),
+                "isa_maskbn_apply_pool")
+        self._att_ctx = dict(sp=sp, e1=e1, e2=e2, am=am, v=v, mean_var=mean_var, merge=merge)
+        return merge
+
+    # ------------------------------------------------------------------ pyramid decoder
+    def _drop_mask(self, n, c, active):
+        if not active or self.drop_rate <= 0:
+            return None
+        keep = 1.0 - self.drop_rate
+        m = (torch.rand(n, c, device=self.E.device) < keep).float() / keep      # host-side RNG plumbing
+        return m.contiguous()
+
+    def level(self, lvl, x_prev: Act, skip: Act, pred_prev: Act, mask_all, s_t, W_full, training, masks):
+        """One UpDecoderLayer (utils.py:869-892).  Returns (x, pred)."""
+        E, net = self.E, self.net
+        pre = "decoder.bone.upAtten%d" % lvl
+        ua = pre + ".UpAtten"
+        n, h, w = skip.n, skip.h, skip.w
+        out_ch, f = OUT_CH[lvl], FACTORS[lvl]
+        nb = int(math.log2(f))
+        naux = 2 * nb + 2
+        ccross = out_ch - naux
+        width = out_ch if lvl == 0 else 2 * out_ch
+        cat = E.new_act(n, h, w, width, ld=width)
+        cross_off = 0 if lvl == 0 else out_ch
+        # cross branch: IR -> Dropout2d(module) -> IR
+        mid = E.new_act(n, h, w, out_ch)
+        net.block_ir(skip, ua + ".cross.up_feature.0", mid, oscale=masks.get("cross"))
+        net.block_ir(mid, ua + ".cross.up_feature.2", cat.slice(cross_off, ccross))
+        up = None
+        if lvl > 0:
+            up = E.new_act(n, h, w, out_ch)
+            E.conv(x_prev, ua + ".up.weight", up, bias=ua + ".up.bias", transposed=True)
+            L.check(E.lib.isa_gate(up.d(), pred_prev.d(), cat.slice(0, out_ch).d(), None, E.st()), "isa_gate")
+        aux = cat.slice(cross_off + ccross, naux)
+        L.check(E.lib.isa_concat_aux(aux.d(), L.ptr(mask_all), L.ptr(s_t), W_full, f, nb, E.st()), "isa_concat_aux")
+        if lvl == 0:
+            kmap = None
+        else:   # physical [gated(out) | cross(ccross) | aux] -> source [cross | gated | aux]
+            kmap = [ccross + k for k in range(out_ch)] + list(range(ccross)) + \
+                   [ccross + out_ch + k for k in range(naux)]
+        y = E.new_act(n, h, w, out_ch)
+        _, s = E.conv(cat, ua + ".conv1.0.weight", y, stats=True, kmap=kmap)
+        x = E.new_act(n, h, w, out_ch)
+        E.bn_out(y, s, ua + ".conv1.1", L.ACT_RELU, x, bscale=masks.get("d1"))
+        x2 = E.new_act(n, h, w, out_ch)
+        net.block_ir(x, ua + ".dilation_part1.0", x2)
+        x3 = E.new_act(n, h, w, out_ch)
+        self._block_ir_ext(x2, ua + ".dilation_part1.1", x3, res2=up, oscale=masks.get("d2"))
+        x4 = E.new_act(n, h, w, out_ch)
+        net.block_ir(x3, ua + ".dilation_part2.0", x4)
+        x5 = E.new_act(n, h, w, out_ch)
+        net.block_ir(x4, ua + ".dilation_part2.1", x5)
+        # L0Layer (utils.py:696-774): conv3x3 -> LeakyReLU -> conv3x3
+        hmid = E.new_act(n, h, w, out_ch // 2)
+        E.conv(x5, pre + ".pred.l_i.weight", hmid, taps=9, bias=pre + ".pred.l_i.bias")
+        pred = E.new_act(n, h, w, 2)
+        E.conv(hmid.with_pro(Pro(act=L.ACT_LEAKY)), pre + ".pred.last_fc.1.weight", pred, taps=9,
+               bias=pre + ".pred.last_fc.1.bias")
+        return x5, pred
+
+    def _block_ir_ext(self, x, pre, out, res2=None, oscale=None):
+        """InvertedResidual whose materialising pass also adds `res2` and applies a Dropout2d mask
+        to the sum (utils.py:1104-1110: x = dilation_part1(x); x = x + x1; x = dropout2d(x))."""
+        E = self.E
+        chid = E.params.shapes[pre + ".conv.0.weight"][0]
+        cout = E.params.shapes[pre + ".conv.6.weight"][0]
+        y1 = E.new_act(x.n, x.h, x.w, chid)
+        _, s1 = E.conv(x, pre + ".conv.0.weight", y1, stats=True)
+        y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
+        y2 = E.new_act(x.n, x.h, x.w, chid)
+        _, s2 = E.dwconv(y1, pre + ".conv.3.weight", y2, stats=True)
+        y2 = E.bn(y2, s2, pre + ".conv.4", L.ACT_RELU6)
+        y3 = E.new_act(x.n, x.h, x.w, cout)
+        _, s3 = E.conv(y2, pre + ".conv.6.weight", y3, stats=True)
+        return E.bn_out(y3, s3, pre + ".conv.7", L.ACT_NONE, out, res=x if x.c == cout else None,
+                        res2=res2, oscale=oscale)
+
+    # ------------------------------------------------------------------ driver (attenet2.py:357-407)
+    def forward(self, x_dec: Act, feats, sem_map: torch.Tensor, ins: torch.Tensor, n_ins, training: bool,
+                selected_idx, injected_s_t=None, capture=None):
+        """sem_map: fp32 [n, h*w] {0,1}; ins: int64 [n,32,h,w] on device; n_ins: host ints;
+        selected_idx[b]: instance order; injected_s_t: optional list of int32 device vectors (train
+        sampling is injected, SURVEY §7 'RNG parity').  Returns dict of per-iteration records."""
+        E = self.E
+        n, H, W = x_dec.n, x_dec.h, x_dec.w
+        Lp = H * W
+        nobj = ins.shape[1]
+        x_enc = self.stems(x_dec)
+        s = self.spatial_attention(x_enc, sem_map)
+        merge = self.hard_attention_scores(s, sem_map)
+        nmin = int(min(int(v) for v in n_ins))
+        max_iter = min(MAX_ITER, nmin) if training else nmin
+        mask_all = []
+        for f in FACTORS:
+            if f == 1:
+                mask_all.append(sem_map)
+            else:
+                m = E.f32(n * (H // f) * (W // f))
+                L.check(E.lib.isa_pool_target(None, None, L.ptr(sem_map), nobj, n, H, W, f, L.ptr(m), E.st()),
+                        "isa_pool_target(sem)")
+                mask_all.append(m)
+        idx_host = torch.tensor([[selected_idx[b][it] for b in range(n)] for it in range(max_iter)],
+                                dtype=torch.int32).reshape(max_iter, n)
+        idx_dev = idx_host.to(E.device)
+        skips = [feats[4], feats[3], feats[2], feats[1], feats[0]]
+        iters = []
+        if capture is not None:
+            capture.update(x_enc=x_enc, s_sp=s, merge=merge)
+        for it in range(max_iter):
+            idx = idx_dev[it]
+            alpha, rowstat = E.f32(n * Lp), E.f32(2 * n)
+            L.check(E.lib.isa_ins_softmax(L.ptr(merge), L.ptr(ins), L.ptr(idx), n, nobj, Lp, L.ptr(alpha),
+                                          L.ptr(rowstat), E.st()), "isa_ins_softmax")
+            if injected_s_t is not None:
+                s_t = injected_s_t[it]
+            else:
+                s_t = E.arena.alloc((n,), torch.int32)
+                L.check(E.lib.isa_row_argmax(L.ptr(alpha), n, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
+            targets = []
+            for f in FACTORS:
+                t = E.f32(n * (H // f) * (W // f))
+                L.check(E.lib.isa_pool_target(L.ptr(ins), L.ptr(idx), None, nobj, n, H, W, f, L.ptr(t), E.st()),
+                        "isa_pool_target")
+                targets.append(t)
+            x, pred = None, None
+            preds, sums = [], []
+            for lvl in range(5):
+                masks = {}
+                if self.drop_rate > 0:
+                    oc = OUT_CH[lvl]
+                    masks = dict(cross=self._drop_mask(n, oc, E.bn_train), d1=self._drop_mask(n, oc, training),
+                                 d2=self._drop_mask(n, oc, training))
+                    masks = {k: v for k, v in masks.items() if v is not None}
+                x, pred = self.level(lvl, x, skips[lvl], pred, mask_all[lvl], s_t, W, training, masks)
+                sm = E.scratch(8 * n)
+                L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None, L.ptr(sm), E.st()),
+                        "isa_mask_loss_sums")
+                preds.append(pred)
+                sums.append(sm)
+                if capture is not None:
+                    capture["it%d.L%d.x" % (it, lvl)] = x
+                    capture["it%d.L%d.pred" % (it, lvl)] = pred
+            iters.append(dict(idx=idx, alpha=alpha, s_t=s_t, targets=targets, preds=preds, sums=sums))
+        return dict(iters=iters, max_iter=max_iter, merge=merge, x_enc=x_enc)
+
+    # ------------------------------------------------------------------ host-side scalar assembly
+    @staticmethod
+    def scalars_from_sums(rec, training, baseline=0.0):
+        """Reference outputs (ins_cost, criterion, ins_ce_loss, ins_dice_loss) from the per-level
+        per-image sums.  Host arithmetic on 5*B*7 floats (validation / logging path; the training
+        path assembles the same quantities on device in isa_head_loss)."""
+        tot = dict(loss=0.0, criterion=0.0, ce=0.0, dice=0.0)
+        nan = False
+        max_iter = rec["max_iter"]
+        for itrec in rec["iters"]:
+            S = [s.view(-1, 8).double().cpu() for s in itrec["sums"]]
+            last = S[-1]
+            nimg = last.shape[0]
+            cnt = last[:, 6]
+            eval_ce = float(last[:, 4].sum() / cnt.sum())
+            dice1 = 1.0 - (2 * last[:, 0] + 1.0) / (last[:, 1] + last[:, 2] + 1.0)
+            if not training:
+                dice2 = 1.0 - (2 * last[:, 0] + 1.0) / (last[:, 5] + last[:, 2] + 1.0)
+                tot["loss"] = tot["loss"] + dice2
+                tot["criterion"] = tot["criterion"] + (eval_ce + dice1)
+            else:
+                nan = True
+                tot["criterion"] = tot["criterion"] + (eval_ce + float(dice1.sum()))
+            tot["ce"] += eval_ce
+            tot["dice"] += float(dice1.mean())
+        out = dict(ins_ce_loss=tot["ce"] / max_iter, ins_dice_loss=tot["dice"] / max_iter)
+        if training:
+            out["ins_cost"] = float("nan")
+            out["criterion"] = float(tot["criterion"]) / max_iter
+        else:
+            out["ins_cost"] = float((tot["loss"] / max_iter).mean())
+            out["criterion"] = float((tot["criterion"] / max_iter).mean())
+        return out

@@ -36,6 +36,7 @@ class IsaPackEntry(C.Structure):
 
 
 P_T, P_PRO, VP, I32, F = C.POINTER(IsaTensor), C.POINTER(IsaPro), C.c_void_p, C.c_int32, C.c_float
+I64 = C.c_int64
 
 # name -> argtypes, exactly mirroring include/isa_kernels.h
 SIGNATURES = {
@@ -49,7 +50,7 @@ SIGNATURES = {
     "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
     "isa_bn_bwd_apply": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP, F, I32, P_T, VP, VP, VP],
-    "isa_affine_act_res": [P_T, P_PRO, P_T, P_T, VP],
+    "isa_affine_act_res": [P_T, P_PRO, P_T, P_T, VP, P_T, VP],
     "isa_axpy": [P_T, P_T, F, I32, VP],
     "isa_avgpool2": [P_T, P_T, VP],
     "isa_avgpool2_bwd": [P_T, P_T, I32, VP],
@@ -58,6 +59,19 @@ SIGNATURES = {
     "isa_chan_mean": [P_T, P_PRO, VP, VP],
     "isa_se_fc": [VP, VP, VP, VP, VP, I32, I32, I32, VP, VP, VP],
     "isa_chan_argmax": [P_T, P_T, VP],
+    "isa_mask_dot": [P_T, VP, VP, VP, VP, VP, VP],
+    "isa_sp_softmax": [VP, VP, VP, VP, VP, VP, I32, I32, I64, VP, VP, VP],
+    "isa_scaled_stats": [P_T, VP, VP, VP],
+    "isa_sp_apply": [P_T, VP, VP, VP, VP, P_T, VP],
+    "isa_maskbn_stats": [P_T, VP, VP, VP, VP],
+    "isa_maskbn_finalize": [VP, VP, I32, I32, VP, VP, VP, F, I32, VP],
+    "isa_maskbn_apply_pool": [P_T, VP, VP, VP, VP, F, VP, VP],
+    "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, VP],
+    "isa_row_argmax": [VP, I32, I64, VP, VP],
+    "isa_pool_target": [VP, VP, VP, I32, I32, I32, I32, I32, VP, VP],
+    "isa_concat_aux": [P_T, VP, VP, I32, I32, I32, VP],
+    "isa_gate": [P_T, P_T, P_T, VP, VP],
+    "isa_mask_loss_sums": [P_T, VP, VP, VP, VP],
     "isa_nchw_to_nhwc": [VP, I32, P_T, VP],
     "isa_nhwc_to_nchw": [P_T, VP, VP],
 }

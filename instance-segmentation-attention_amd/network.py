@@ -32,9 +32,10 @@ class Network:
         _, s2 = E.conv(y1, pre + ".conv.3.weight", y2, stats=True)
         return E.bn_out(y2, s2, pre + ".conv.4", L.ACT_NONE, out, res=x if cin == cout else None)
 
-    def block_ir(self, x: Act, pre: str, out: Act, bscale=None, extra_res: Act = None):
+    def block_ir(self, x: Act, pre: str, out: Act, oscale=None):
         """InvertedResidual (MobileNetDenseASPP.py:96-123): pw-BN-ReLU6-dw-BN-ReLU6-pw-BN (+x).
-        `bscale` folds a following Dropout2d into the materialising pass."""
+        `oscale` folds a following Dropout2d (which scales the block output, residual included)
+        into the materialising pass."""
         E = self.E
         cin = x.c
         chid = E.params.shapes[pre + ".conv.0.weight"][0]
@@ -48,7 +49,7 @@ class Network:
         y3 = E.new_act(x.n, x.h, x.w, cout)
         _, s3 = E.conv(y2, pre + ".conv.6.weight", y3, stats=True)
         return E.bn_out(y3, s3, pre + ".conv.7", L.ACT_NONE, out, res=x if cin == cout else None,
-                        bscale=bscale)
+                        oscale=oscale)
 
     def double_v1(self, x: Act, pre: str, out: Act):
         E = self.E

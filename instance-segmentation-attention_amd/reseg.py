@@ -1,0 +1,157 @@
+"""Drop-in `ReSeg` (reference: code/lib/archs/reseg.py:52-130).
+
+Same constructor signature, same `forward(training, *_input)` contract, same `state_dict()` keys,
+shapes and order (891 tensors), `.base` attribute, `.parameters()`, `.train()/.eval()`, `.cuda()`.
+All compute runs in the HIP library behind include/isa_kernels.h; this class only owns the
+parameters (views into one flat fp32 buffer, so DDP needs one all-reduce and the optimizer one
+kernel) and sequences launches.  Missing library or missing GPU => hard error, never a fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .engine import Engine, ParamStore
+from .network import Network
+from .schema import state_dict_schema
+
+
+class _Node(nn.Module):
+    """Anonymous container reproducing the reference's module tree for state_dict naming."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("container node: compute lives in the HIP engine")
+
+
+class ReSeg(nn.Module):
+    def __init__(self, n_classes, use_instance_seg=True, pretrained=True, use_coordinates=False,
+                 use_wae=True, usegpu=True, training=True, dtype=torch.float32, device=None):
+        super().__init__()
+        assert n_classes == 2, "the reference head is built for 2 classes (data_settings.py:19)"
+        if not torch.cuda.is_available():
+            raise RuntimeError("ReSeg (MI355X build) needs a GPU: there is no CPU fallback")
+        L.lib()                                   # fail loudly if the HIP library is missing
+        self.backbone = "Unet"
+        self.n_classes = n_classes
+        self.use_instance_seg = use_instance_seg
+        self.use_wae = use_wae
+        self.compute_dtype = dtype
+        dev = torch.device(device or "cuda")
+        self.store = ParamStore(state_dict_schema(use_instance_seg), dev)
+        self._build_tree()
+        self.engine = Engine(self.store, dtype, dev)
+        self.net = Network(self.engine, use_instance_seg)
+        self.reset_parameters()
+        self.train(training)
+
+    # ------------------------------------------------------------------ module tree
+    def _build_tree(self):
+        st = self.store
+        self._nbt = {}
+        for name in st.names:
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Node())
+                mod = mod._modules[p]
+            leaf = parts[-1]
+            if leaf == "num_batches_tracked":
+                buf = torch.zeros((), dtype=torch.long)
+                mod.register_buffer(leaf, buf)
+                self._nbt[name] = (mod, leaf)
+            elif leaf in ("running_mean", "running_var"):
+                mod.register_buffer(leaf, st.view(name))
+            else:
+                p_ = nn.Parameter(st.view(name))
+                p_.grad = st.gview(name)
+                mod.register_parameter(leaf, p_)
+
+    def reset_parameters(self, seed=None):
+        """Fresh weights in the spirit of torch defaults (kaiming-uniform convs, BN gamma=1/beta=0,
+        maskBN gamma~U(0,1) as utils.py:561).  Host-side plumbing on the flat buffer views."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0 if seed is None else int(seed))
+        st = self.store
+        bn_prefixes = {n[:-len(".running_mean")] for n in st.names if n.endswith(".running_mean")}
+        for name in st.names:
+            if name in st.int_buffers:
+                continue
+            v, shape = st.view(name), st.shapes[name]
+            prefix, leaf = name.rsplit(".", 1)
+            if leaf == "running_mean":
+                v.zero_()
+            elif leaf == "running_var":
+                v.fill_(1.0)
+            elif prefix in bn_prefixes and leaf == "weight":
+                v.copy_(torch.rand(shape, generator=g)) if prefix == "decoder.attend.bn" else v.fill_(1.0)
+            elif prefix in bn_prefixes and leaf == "bias":
+                v.zero_()
+            else:
+                fan_in = 1
+                for d in (shape[1:] if len(shape) > 1 else shape):
+                    fan_in *= d
+                if leaf == "bias":                       # conv/linear bias: fan-in of its weight
+                    wshape = st.shapes.get(prefix + ".weight", shape)
+                    fan_in = 1
+                    for d in wshape[1:]:
+                        fan_in *= d
+                bound = (1.0 / max(fan_in, 1)) ** 0.5
+                v.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _apply(self, fn, recurse=True):
+        # parameters are views of one flat device buffer; moving/casting them individually would
+        # break that.  `.cuda()` / `.to(same device)` are accepted as no-ops like the reference's
+        # `model.cuda()` call site (model.py:52).
+        probe = fn(torch.empty(0, device=self.store.device))
+        if probe.device != self.store.device or probe.dtype != torch.float32:
+            raise RuntimeError("ReSeg parameters live in one flat fp32 GPU buffer; cannot move/cast")
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        for name, (mod, leaf) in self._nbt.items():
+            mod._buffers[leaf].fill_(self.store.int_buffers[name])
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        for name, (mod, leaf) in self._nbt.items():
+            self.store.int_buffers[name] = int(mod._buffers[leaf])
+        self.engine.packer.table = None if self.engine.packer.entries else self.engine.packer.table
+        self._weights_dirty = True
+        return out
+
+    def mark_weights_dirty(self):
+        """Call after an optimizer step changed the flat parameter buffer (repack on next forward)."""
+        self._weights_dirty = True
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, training, *_input):
+        E, net = self.engine, self.net
+        if len(_input) == 4:
+            x, sem_seg_target, ins_seg_target, N = _input
+        else:
+            x = _input[0]
+        assert x.dim() == 4 and x.shape[1] == 21, "expects [B,21,H,W] (ImageEx tensor, utils.py:109)"
+        assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
+        x = x.to(device=self.store.device, dtype=torch.float32)
+        E.begin(bn_train=self.training, record=False)
+        if getattr(self, "_weights_dirty", True) and E.packer.entries:
+            E.packer.pack()
+        self._weights_dirty = False
+        xin = net.to_nhwc(x)
+        x_dec, feats = net.unet(xin)
+        sem = net.sem_head(x_dec)
+        sem_out = net.to_nchw(sem)
+        if len(_input) == 4:
+            sem_argmax = sem_seg_target.to(self.store.device).argmax(1).unsqueeze(1).float()
+        else:
+            sem_argmax = net.to_nchw(net.argmax_map(sem))
+        if self.use_instance_seg:
+            if len(_input) != 4:
+                # the reference raises UnboundLocalError here (reseg.py:126): the instance head
+                # needs ground-truth masks and has no GT-free mode
+                raise RuntimeError("instance head needs (x, sem, ins, N); build ReSeg(.., use_instance_seg=False) "
+                                   "for GT-free inference")
+            raise NotImplementedError("instance head forward is wired in instance_head.py")
+        return sem_out, sem_argmax
