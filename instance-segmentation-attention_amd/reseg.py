@@ -12,6 +12,7 @@ import torch.nn as nn
 from . import lib as L
 from .engine import Engine, ParamStore
 from .network import Network
+from .instance_head import InstanceHead
 from .schema import state_dict_schema
 
 
@@ -36,10 +37,13 @@ class ReSeg(nn.Module):
         self.use_wae = use_wae
         self.compute_dtype = dtype
         dev = torch.device(device or "cuda")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.store = ParamStore(state_dict_schema(use_instance_seg), dev)
         self._build_tree()
         self.engine = Engine(self.store, dtype, dev)
         self.net = Network(self.engine, use_instance_seg)
+        self.head = InstanceHead(self.net)
         self.reset_parameters()
         self.train(training)
 
@@ -126,15 +130,23 @@ class ReSeg(nn.Module):
         self._weights_dirty = True
 
     # ------------------------------------------------------------------ forward
-    def forward(self, training, *_input):
+    def forward(self, training, *_input, selected_idx=None, injected_s_t=None, capture=None):
+        """reseg.py:106-130.  (x) -> (sem_out, sem_argmax);  (x, sem_onehot[B,2,H,W] i64,
+        ins[B,32,H,W] i64, N[B,1]) -> (sem_out, sem_argmax, ins_cost, criterion, ins_ce_loss,
+        ins_dice_loss).  BatchNorm mode follows .train()/.eval() like the reference modules; the
+        `training` flag drives sampling, F.dropout2d and the loss branch (attenet2.py:377-399).
+        `selected_idx` / `injected_s_t` inject the reference's host RNG choices (random.shuffle,
+        torch.multinomial) for parity runs; defaults: random order / argmax-or-sampled on device."""
         E, net = self.engine, self.net
-        if len(_input) == 4:
+        has_gt = len(_input) == 4
+        if has_gt:
             x, sem_seg_target, ins_seg_target, N = _input
         else:
             x = _input[0]
         assert x.dim() == 4 and x.shape[1] == 21, "expects [B,21,H,W] (ImageEx tensor, utils.py:109)"
         assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
-        x = x.to(device=self.store.device, dtype=torch.float32)
+        dev = self.store.device
+        x = x.to(device=dev, dtype=torch.float32)
         E.begin(bn_train=self.training, record=False)
         if getattr(self, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
@@ -143,15 +155,31 @@ class ReSeg(nn.Module):
         x_dec, feats = net.unet(xin)
         sem = net.sem_head(x_dec)
         sem_out = net.to_nchw(sem)
-        if len(_input) == 4:
-            sem_argmax = sem_seg_target.to(self.store.device).argmax(1).unsqueeze(1).float()
+        if has_gt:
+            sem_argmax = sem_seg_target.to(dev).argmax(1).unsqueeze(1).float()
         else:
             sem_argmax = net.to_nchw(net.argmax_map(sem))
-        if self.use_instance_seg:
-            if len(_input) != 4:
-                # the reference raises UnboundLocalError here (reseg.py:126): the instance head
-                # needs ground-truth masks and has no GT-free mode
-                raise RuntimeError("instance head needs (x, sem, ins, N); build ReSeg(.., use_instance_seg=False) "
-                                   "for GT-free inference")
-            raise NotImplementedError("instance head forward is wired in instance_head.py")
-        return sem_out, sem_argmax
+        if not self.use_instance_seg:
+            return sem_out, sem_argmax
+        if not has_gt:
+            # the reference raises UnboundLocalError here (reseg.py:126): the instance head needs
+            # ground-truth masks and has no GT-free mode
+            raise RuntimeError("instance head needs (x, sem, ins, N); build ReSeg(.., use_instance_seg=False) "
+                               "for GT-free inference")
+        n_ins = [int(v) for v in N.reshape(-1).tolist()]
+        if selected_idx is None:
+            import random
+            selected_idx = []
+            for k in n_ins:                       # attenet2.py:349-355
+                order = list(range(k))
+                random.shuffle(order)
+                selected_idx.append(order)
+        sem_map = sem_argmax.reshape(x.shape[0], -1).contiguous()
+        ins_dev = ins_seg_target.to(dev).contiguous()
+        rec = self.head.forward(x_dec, feats, sem_map, ins_dev, n_ins, bool(training), selected_idx,
+                                injected_s_t, capture)
+        self.last_record = rec
+        sc = self.head.scalars_from_sums(rec, bool(training))
+        t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+        return (sem_out, sem_argmax, t(sc["ins_cost"]), t(sc["criterion"]), t(sc["ins_ce_loss"]),
+                t(sc["ins_dice_loss"]))
