@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec at 256x256, bs=16 per GPU, synthetic data, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` = whole-job images/s with
+inputs resident in HBM.  Workloads:
+  train_step : forward + backward + grad all-reduce (N>1) + fused Adadelta   [default when built]
+  train_fwd  : ReSeg.forward(True, x, sem, ins, N) — conv backbone + attention mask head, 2 iterations
+  infer      : ReSeg(False, x) sem-only inference (configs[2])
+Extra objects: `roofline` (dominant kernel family, HIP-event timed in an instrumented extra step on
+the launch stream; algorithmic bytes = input read once + output written once per conv)
+and `cpu_baseline` (the CPU oracle = port of the reference path, timed on the host cores on a
+bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+# SURVEY.md §8(d) contract figures, bytes per image at 256^2 in bf16 (x2 for fp32 storage)
+ALG_BYTES_PER_IMAGE_BF16 = {"infer": 161.7e6, "train_fwd": 1.071e9, "train_step": 3.2e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "train_fwd", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    def log(msg):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import torch
+    import torch.distributed as dist
+    import isa_amd  # noqa: F401
+    from isa_amd.reseg import ReSeg
+    import reseg_ref as R
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    workload = args.workload
+    try:
+        from isa_amd.trainer import Trainer
+        have_trainer = True
+    except ImportError:
+        have_trainer = False
+    if workload == "auto":
+        workload = "train_step" if have_trainer else "train_fwd"
+
+    use_ins = workload != "infer"
+    model = ReSeg(2, use_ins, dtype=dtype)
+    model.load_state_dict(R.synth_state_dict(23, use_ins))       # random-init weights (deterministic)
+    B, S = args.batch, args.size
+    x, sem, ins, n = R.synth_batch(B, S, S, seed=100 + rank)     # per-rank shard of the global batch
+    x, sem, ins = x.cuda(), sem.cuda(), ins.cuda()
+    sel = [list(range(int(k))) for k in n.view(-1)]
+
+    trainer = None
+    if workload == "train_step":
+        model.train()
+        trainer = Trainer(model, world_size=world)
+
+        def step():
+            trainer.train_step(x, sem, ins, n, selected_idx=sel)
+    elif workload == "train_fwd":
+        model.train()
+
+        def step():
+            model(True, x, sem, ins, n, selected_idx=sel)
+    else:
+        model.eval()
+
+        def step():
+            model(False, x)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("workload=%s dtype=%s world=%d: warmup" % (workload, args.dtype, world))
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    log("%.2f ms/step, %.1f img/s" % (ms, value))
+
+    out = {
+        "metric": "images/sec @256x256 bs=16 per GPU",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%s %dx%d bs=%d/GPU (%s)" % (
+            {"train_step": "train.py step fwd+bwd+update", "train_fwd": "ReSeg.forward(training) conv+attention head",
+             "infer": "pred_list batched inference"}[workload], S, S, B, args.dtype),
+            "global_batch": world * B, "image": [S, S], "parallelism": "dp%d" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline: one extra instrumented step, events on the launch stream -----------------
+        E = model.engine
+        E.profile = True
+        step()
+        prof = E.profile_summary()
+        E.profile = False
+        fam = {k: v for k, v in prof.items() if v[2] > 0}
+        if fam:
+            dom = max(fam.items(), key=lambda kv: kv[1][1])
+            name, (calls, tot_ms, nbytes) = dom
+            achieved = nbytes / (tot_ms * 1e-3) / 1e9
+            esz = 2 if args.dtype == "bf16" else 4
+            step_bytes = ALG_BYTES_PER_IMAGE_BF16[workload] * (esz / 2) * (S * S) / 65536.0
+            out["roofline"] = {
+                "bound": "hbm", "kernel": name, "launches_per_step": calls,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(tot_ms * 1e3 / calls, 2),
+                "alg_bytes_per_launch": int(nbytes / calls),
+                "step_frac": round(value / world * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                "families_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]},
+            }
+        # ---- CPU baseline: the oracle (port of the reference path) on a bounded sample ----------
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            torch.set_num_threads(max(1, min(ncpu, 16)))      # the GPU box gives one GPU a 16-core share
+            log("cpu baseline on %d threads" % torch.get_num_threads())
+            cb = 2
+            cx, csem, cins, cn = R.synth_batch(cb, S, S, seed=7)
+            sd = R.synth_state_dict(23, True)
+            csel = [list(range(int(k))) for k in cn.view(-1)]
+            pick = (lambda a: a.argmax(1))
+
+            def cpu_step():
+                if workload == "infer":
+                    with torch.no_grad():
+                        R.reseg_forward(sd, cx, use_instance_seg=False)
+                elif workload == "train_fwd":
+                    with torch.no_grad():
+                        R.reseg_forward(sd, cx, csem, cins, cn, ctx=R.Ctx(bn_train=True, training=True, drop_rate=0.0),
+                                        state=R.HeadState(), selected_idx=csel, sample_fn=pick)
+                else:
+                    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+                         for k, v in sd.items()}
+                    o = R.reseg_forward(P, cx, csem, cins, cn, ctx=R.Ctx(bn_train=True, training=True, drop_rate=0.0),
+                                        state=R.HeadState(), selected_idx=csel, sample_fn=pick)
+                    ce, dice = R.sem_losses(o["sem_out"], csem)
+                    (o["ins_cost_finite"] + ce + dice).backward()
+
+            cpu_step()
+            log("cpu baseline warm rep done")
+            reps, t1 = 0, time.perf_counter()
+            while reps < 2 or (time.perf_counter() - t1 < 10.0 and reps < 20):
+                cpu_step()
+                reps += 1
+            cdt = (time.perf_counter() - t1) / reps
+            out["cpu_baseline"] = {"value": round(cb / cdt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": "%d reps of the same workload at bs=%d %dx%d fp32 (oracle)" % (
+                                       reps, cb, S, S)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

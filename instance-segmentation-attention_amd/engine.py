@@ -304,6 +304,35 @@ class GradBook:
         return full
 
 
+class _ProfiledLib:
+    """Pass-through to the ctypes library; in profile mode brackets each launch with events on the
+    launch stream so bench.py can report per-kernel-family durations measured live."""
+
+    def __init__(self, lib, eng):
+        self._lib, self._eng = lib, eng
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        eng = self._eng
+
+        def call(*args):
+            if not eng.profile:
+                return fn(*args)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            eng.prof_events.append((name, s, e, eng.next_bytes))
+            eng.next_bytes = 0
+            return rc
+
+        self._cache[name] = call
+        setattr(self, name, call)
+        return call
+
+
 class Engine:
     BN_EPS = 1e-5
     BN_MOMENTUM = 0.1
@@ -322,7 +351,10 @@ class Engine:
         self.stats_cursor = 0
         self.stats_size = 0
         self._zero = None
-        self.lib = L.lib()
+        self.lib = _ProfiledLib(L.lib(), self)
+        self.profile = False           # when True every launch is bracketed by HIP events
+        self.prof_events = []          # (entry point, start event, end event, algorithmic bytes)
+        self.next_bytes = 0
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool):
@@ -431,6 +463,9 @@ class Engine:
     def _launch_conv(self, x, reg, bias, out, in_mode, out_mode, st):
         if self.packer.table is None:
             self.packer.pack()
+        if self.profile:     # algorithmic bytes: input read once + output written once
+            esz = x.buf.element_size()
+            self.next_bytes = (x.n * x.h * x.w * x.c + out.n * out.h * out.w * out.c) * esz
         L.check(self.lib.isa_conv_gemm(x.d(), x.p(), self.packer.ptr(reg["fwd"]), reg["kp"],
                                        self.params.ptr(bias) if bias else None, out.d(), in_mode, out_mode,
                                        L.ptr(st), 0, self.st()), "isa_conv_gemm")
@@ -447,6 +482,8 @@ class Engine:
         if self.packer.table is None:
             self.packer.pack()
         st = self.scratch(2 * out.c) if stats else None
+        if self.profile:
+            self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
         L.check(self.lib.isa_dwconv3x3(x.d(), x.p(), self.packer.ptr(reg["fwd"]),
                                        self.params.ptr(bias) if bias else None, out.d(), L.ptr(st), self.st()),
                 "isa_dwconv3x3")
@@ -553,6 +590,16 @@ class Engine:
                 L.check(self.lib.isa_avgpool2_bwd(self.grads.grad_of(out).d(), self.grads.grad_of(x).d(), acc,
                                                   self.st()), "isa_avgpool2_bwd")
             self.tape.append(bwd)
+        return out
+
+    def profile_summary(self):
+        """{entry point: (calls, total ms, algorithmic bytes)} from the recorded events."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, nbytes in self.prof_events:
+            c, t, b = out.get(name, (0, 0.0, 0))
+            out[name] = (c + 1, t + s.elapsed_time(e), b + nbytes)
+        self.prof_events = []
         return out
 
     # ------------------------------------------------------------------ backward driver
