@@ -147,8 +147,10 @@ int isa_avgpool2(const isa_tensor* x, const isa_tensor* y, void* stream);
 int isa_avgpool2_bwd(const isa_tensor* dy, const isa_tensor* dx, int32_t accumulate, void* stream);
 /* f x f max / mean pooling with stride f of small-channel maps (utils.py:841-846) */
 int isa_pool_f(const isa_tensor* x, const isa_tensor* y, int32_t f, int32_t is_max, void* stream);
-/* 3x3 mean, stride 1, pad 1, count_include_pad (utils.py:634,645); optional per-pixel mask mul */
-int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* y, void* stream);
+/* 3x3 mean, stride 1, pad 1, count_include_pad (utils.py:634,645); optional per-pixel mask mul;
+ * y (+)= ...: the operator is self-adjoint, so the same call with accumulate is its backward */
+int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* y, int32_t accumulate,
+                 void* stream);
 
 /* ---- squeeze-excite gate + heads (utils.py:402-420, reseg.py:72-75,116-120) ------------------ */
 /* mean over h*w of pro(x): out[n,c] */
@@ -195,6 +197,42 @@ int isa_gate(const isa_tensor* up, const isa_tensor* pred, const isa_tensor* out
  * sums[b][0..6] = {sum p1*t, sum p1, sum t, sum focal, sum ce, sum p1^2, count}; stride 8 floats */
 int isa_mask_loss_sums(const isa_tensor* pred, const float* target, const int64_t* onehot, float* sums,
                        void* stream);
+
+/* ---- losses and hand-derived backward of the head (the reference relies on autograd) ------------
+ * isa_head_loss: attenet2.py:239-290 on device (no host sync): per-level gradient coefficients,
+ * REINFORCE advantage with the EMA baseline (device scalar), and scal[0..3] += {ins_cost without the
+ * NaN entropy term (attenet2.py:77, zero gradient), criterion, ins_ce_loss, ins_dice_loss}/max_iter. */
+int isa_head_loss(const float* sums /*[5][B][8]*/, const float* alpha, const int32_t* s_t, int64_t L, int32_t B,
+                  const float* level_w /*host[5]*/, float ce_weight, float lambda_l, float lambda_r, float inv_iter,
+                  float* baseline, int32_t training, float* coef /*[5][B][4]*/, float* adv /*[B]*/,
+                  float* scal /*[4]*/, void* stream);
+/* trainer-side CE + Dice on the semantic logits (model.py:255-269): scal = {ce, dice}, coef[B][4] */
+int isa_sem_loss(const float* sums /*[B][8]*/, int32_t B, float* coef, float* scal, void* stream);
+int isa_mask_loss_grad(const isa_tensor* pred, const float* target, const int64_t* onehot, const float* coef /*[B][4]*/,
+                       const isa_tensor* dpred, int32_t accumulate, void* stream);
+int isa_ins_softmax_bwd(const float* alpha, const int64_t* ins, const int32_t* idx, const int32_t* s_t,
+                        const float* adv, int32_t n, int32_t nobj, int64_t L, float* dmerge, void* stream);
+int isa_maskbn_bwd(const isa_tensor* e, const float* sem, const float* dmerge, const float* mean_var,
+                   const float* w, float eps, const float* am, int32_t train, float* red4 /*zeroed*/, float* k2,
+                   float* dw, float* db, const isa_tensor* de, int32_t accumulate, void* stream);
+int isa_sp_bwd(const isa_tensor* dout, const isa_tensor* x, const float* beta, const float* m, const float* dot,
+               const float* rowstat, const float* chansum, const float* scale, const float* mean,
+               const float* invstd, const float* wv, const float* lh, const float* fcw, float count, int32_t train,
+               float* scratch /*zeroed: 3C + rup(n,4) + 2*n*L floats*/, const isa_tensor* dx, int32_t accumulate,
+               float* d_gamma, float* d_beta, float* d_wv, float* d_bv, float* d_lh, float* d_fcw, float* d_fcb,
+               void* stream);
+int isa_gate_bwd(const isa_tensor* dout, const isa_tensor* up, const float* gmap, const isa_tensor* dup,
+                 int32_t acc_up, float* du /*zeroed [n*H*W]*/, const isa_tensor* dpred, int32_t acc_pred, void* stream);
+int isa_se_bwd(const isa_tensor* dxa, const isa_tensor* x, const float* gate, const float* hid, const float* mean,
+               const float* w1, const float* w2, int32_t hidden, float* dg /*zeroed [n*c]*/, float* dmean /*[n*c]*/,
+               float* dw1, float* db1, float* dw2, float* db2, const isa_tensor* dx, int32_t accumulate, void* stream);
+/* dst (+)= src * s[n,c]  (Dropout2d backward on a residual sum) */
+int isa_scale_bc(const isa_tensor* src, const float* s_bc, const isa_tensor* dst, int32_t accumulate, void* stream);
+/* optimizer on the flat parameter buffer (model.py:145-166,273-278): out += sum (g*scale)^2, then
+ * clip_grad_norm_(max_norm) + Adadelta(lr, rho, eps, weight_decay) in one pass */
+int isa_sqnorm(const float* g, int64_t n, float scale, float* out /*zeroed*/, void* stream);
+int isa_adadelta(float* p, const float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps, float wd,
+                 const float* sqnorm, float max_norm, float gscale, void* stream);
 
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);

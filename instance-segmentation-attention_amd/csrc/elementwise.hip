@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void pool_f_kernel(PoolParams p) {
 }
 
 // 3x3 mean, stride 1, pad 1, divisor always 9; optional single-channel mask multiply
-struct Pool3Params { View x, mask, y; int has_mask; };
+struct Pool3Params { View x, mask, y; int has_mask; int accumulate; };
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool3_kernel(Pool3Params p) {
     const long items = (long)p.y.n * p.y.h * p.y.w * p.y.c;
@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(Pool3Params p) {
         acc *= (1.f / 9.f);
         const long pix = ((long)b * p.y.h + yo) * p.y.w + xo;
         if (p.has_mask) acc *= st<T>::ld(reinterpret_cast<const T*>(p.mask.data) + pix * p.mask.ld);
-        st<T>::stv(reinterpret_cast<T*>(p.y.data) + pix * p.y.ld + c, acc);
+        T* o = reinterpret_cast<T*>(p.y.data) + pix * p.y.ld + c;
+        if (p.accumulate) acc += st<T>::ld(o);
+        st<T>::stv(o, acc);
     }
 }
 
@@ -575,11 +577,11 @@ extern "C" int isa_pool_f(const isa_tensor* x, const isa_tensor* y, int32_t f, i
 }
 
 extern "C" int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* y,
-                            void* stream) {
+                            int32_t accumulate, void* stream) {
     if (!tensor_ok(x, 1) || !tensor_ok(y, 1) || !same_shape(x, y)) return ISA_EINVAL;
     if (mask && (!tensor_ok(mask, 1) || mask->n != x->n || mask->h != x->h || mask->w != x->w ||
                  mask->dtype != x->dtype)) return ISA_EINVAL;
-    Pool3Params p{mkview(x), mask ? mkview(mask) : View{}, mkview(y), mask != nullptr};
+    Pool3Params p{mkview(x), mask ? mkview(mask) : View{}, mkview(y), mask != nullptr, accumulate};
     const int grid = grid_cap(cdiv((long)y->n * y->h * y->w * y->c, 256));
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(avgpool3_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),

@@ -109,22 +109,38 @@ class ParamStore:
     """All parameters and float buffers in ONE flat fp32 tensor (reference state_dict layout per
     tensor) and their gradients in another: one RCCL all-reduce, one optimizer kernel."""
 
+    NEVER_GRAD_PREFIXES = ("decoder.pred.", "decoder.attend.l2.", "decoder.embedding.")   # SURVEY §7: 9 tensors
+
     def __init__(self, schema: List[Tuple[str, tuple]], device):
         self.device = device
         self.names = [n for n, _ in schema]
         self.shapes = {n: tuple(s) for n, s in schema}
         self.offsets: Dict[str, int] = {}
-        off = 0
         self.int_buffers: Dict[str, int] = {}
-        for n, s in schema:
+
+        def klass(n):
             if n.endswith("num_batches_tracked"):
+                return 3
+            if n.endswith("running_mean") or n.endswith("running_var"):
+                return 2
+            return 1 if n.startswith(self.NEVER_GRAD_PREFIXES) else 0
+
+        off = 0
+        self.n_train = 0
+        for k in (0, 1, 2):          # flat layout: [trainable | never-grad params | float buffers]
+            for n, s in schema:
+                if klass(n) != k:
+                    continue
+                self.offsets[n] = off
+                numel = 1
+                for d in s:
+                    numel *= d
+                off += rup(numel, 4)          # keep every tensor 16-byte aligned
+            if k == 0:
+                self.n_train = off
+        for n, _ in schema:
+            if klass(n) == 3:
                 self.int_buffers[n] = 0
-                continue
-            self.offsets[n] = off
-            numel = 1
-            for d in s:
-                numel *= d
-            off += rup(numel, 4)          # keep every tensor 16-byte aligned
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -423,7 +439,7 @@ class Engine:
         return dict(fwd=f, dgrad=b, kp=kp, kp_d=rup(n, 32), n=n, kphys=kphys)
 
     def conv(self, x: Act, wname, out: Act, *, taps=1, bias=None, stats=False, kmap=None,
-             transposed=False):
+             transposed=False, record_bwd=True):
         """out(raw) = conv(pro(x)).  Returns (out, stats tensor or None)."""
         reg = self.reg_conv(wname, taps, kmap, transposed)
         in_mode = L.IN_3X3 if taps == 9 else L.IN_1X1
@@ -431,7 +447,8 @@ class Engine:
         st = self.scratch(2 * out.c) if stats else None
         job = (x, reg, bias, out, in_mode, out_mode, st)
         self._launch_conv(*job)
-        if self.record:
+        self._last_conv = dict(reg=reg, in_mode=in_mode)
+        if self.record and record_bwd:
             def bwd():
                 dy = self.grads.grad_of(out)
                 pk = self.packer
@@ -565,14 +582,31 @@ class Engine:
         if self.record:
             def bwd():
                 dout = self.grads.grad_of(out)
-                if res is not None and res.needs_grad:
-                    acc = self.grads.claim(res, self)
-                    L.check(self.lib.isa_axpy(dout.d(), self.grads.grad_of(res).d(), 1.0, acc, self.st()),
-                            "isa_axpy(res)")
+                dsum = dout
+                if oscale is not None:           # d(sum) = dout * dropout mask
+                    dsum = self.new_act(out.n, out.h, out.w, out.c)
+                    L.check(self.lib.isa_scale_bc(dout.d(), L.ptr(oscale), dsum.d(), 0, self.st()), "isa_scale_bc")
+                for r in (res, res2):
+                    if r is not None and r.needs_grad:
+                        acc = self.grads.claim(r, self)
+                        L.check(self.lib.isa_axpy(dsum.d(), self.grads.grad_of(r).d(), 1.0, acc, self.st()),
+                                "isa_axpy(res)")
                 self.grads.claim(raw, self)       # single consumer: overwrite
-                self._bn_backward(lazy, dout, self.grads.grad_of(raw), bscale)
+                self._bn_backward(lazy, dsum, self.grads.grad_of(raw), bscale)
             self.tape.append(bwd)
         return out
+
+    def act(self, raw: Act, act) -> Act:
+        """Lazy activation without BN (tanh / LeakyReLU after a biased conv).  The gradient w.r.t.
+        the activated value is converted in place to the gradient w.r.t. `raw`."""
+        lazy = raw.with_pro(Pro(act=act))
+        if self.record:
+            def bwd():
+                g = self.grads.grad_of(raw)
+                L.check(self.lib.isa_bn_bwd_apply(g.d(), raw.d(), None, None, None, None, act, None, None, None, 1.0,
+                                                  0, g.d(), None, None, self.st()), "isa_bn_bwd_apply(act)")
+            self.tape.append(bwd)
+        return lazy
 
     def materialize(self, x: Act, out: Act, res: Optional[Act] = None):
         """out = pro(x) (+res) for a lazy x that is NOT a BN output (bias+act convs)."""

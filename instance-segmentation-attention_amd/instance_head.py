@@ -35,6 +35,8 @@ class InstanceHead:
         self.net = net
         self.E: Engine = net.E
         self.drop_rate = DROP_RATE
+        import ctypes as _C
+        self._level_w = (_C.c_float * 5)(*PYRAMID_W)
         self.baseline = None            # device scalar (REINFORCE EMA baseline, attenet2.py:47,266)
 
     # ------------------------------------------------------------------ stems (reseg.py:78-102)
@@ -84,8 +86,21 @@ class InstanceHead:
         out = E.new_act(n, x.h, x.w, c)
         L.check(E.lib.isa_sp_apply(x.d(), L.ptr(beta), L.ptr(sem), L.ptr(scale), L.ptr(shift), out.d(), E.st()),
                 "isa_sp_apply")
-        self._sp_ctx = dict(x=x, dot=dot, chansum=chansum, beta=beta, rowstat=rowstat, scale=scale, shift=shift,
-                            mean=mean, invstd=invstd, out=out)
+        if E.record:
+            train = 1 if E.bn_train else 0
+
+            def bwd():
+                scr = E.scratch(3 * c + (n + 3) // 4 * 4 + 2 * n * Lp)
+                acc = E.grads.claim(x, E)
+                L.check(E.lib.isa_sp_bwd(E.grads.grad_of(out).d(), x.d(), L.ptr(beta), L.ptr(sem), L.ptr(dot),
+                                         L.ptr(rowstat), L.ptr(chansum), L.ptr(scale), L.ptr(mean), L.ptr(invstd),
+                                         P.ptr(pre + ".l_v.weight"), P.ptr(pre + ".l_h.weight"),
+                                         P.ptr(pre + ".spatial_fc.1.weight"), float(n * Lp), train, L.ptr(scr),
+                                         E.grads.grad_of(x).d(), acc, P.gptr(pre + ".bn.weight"), P.gptr(pre + ".bn.bias"),
+                                         P.gptr(pre + ".l_v.weight"), P.gptr(pre + ".l_v.bias"), P.gptr(pre + ".l_h.weight"),
+                                         P.gptr(pre + ".spatial_fc.1.weight"), P.gptr(pre + ".spatial_fc.1.bias"),
+                                         E.st()), "isa_sp_bwd")
+            E.tape.append(bwd)
         return out
 
     # ------------------------------------------------------------------ a8/a9 HardAttentionLayer front
@@ -95,12 +110,17 @@ class InstanceHead:
         n, h, w = s.n, s.h, s.w
         pre = "decoder.attend"
         sp = E.new_act(n, h, w, s.c)
-        L.check(E.lib.isa_avgpool3(s.d(), None, sp.d(), E.st()), "isa_avgpool3")
+        L.check(E.lib.isa_avgpool3(s.d(), None, sp.d(), 0, E.st()), "isa_avgpool3")
+        if E.record:
+            def bwd_pool():      # 3x3 mean with zero padding is self-adjoint
+                acc = E.grads.claim(s, E)
+                L.check(E.lib.isa_avgpool3(E.grads.grad_of(sp).d(), None, E.grads.grad_of(s).d(), acc, E.st()),
+                        "isa_avgpool3(bwd)")
+            E.tape.append(bwd_pool)
         e1 = E.new_act(n, h, w, 12)
         E.conv(sp, pre + ".l1.weight", e1, bias=pre + ".l1.bias")
         e2 = E.new_act(n, h, w, 1)
-        E.conv(e1.with_pro(Pro(act=L.ACT_TANH)), pre + ".attend_fc.1.weight", e2, taps=9,
-               bias=pre + ".attend_fc.1.bias")
+        E.conv(E.act(e1, L.ACT_TANH), pre + ".attend_fc.1.weight", e2, taps=9, bias=pre + ".attend_fc.1.bias")
         am, v, mean_var = E.f32(2 * n), E.f32(n), E.f32(2)
         train = 1 if E.bn_train else 0
         rm, rv = P.ptr(pre + ".bn.running_mean"), P.ptr(pre + ".bn.running_var")
@@ -117,7 +137,19 @@ class InstanceHead:
         L.check(E.lib.isa_maskbn_apply_pool(e2.d(), L.ptr(sem), L.ptr(mean_var), P.ptr(pre + ".bn.weight"),
                                             P.ptr(pre + ".bn.bias"), E.BN_EPS, L.ptr(merge), E.st()),
                 "isa_maskbn_apply_pool")
-        self._att_ctx = dict(sp=sp, e1=e1, e2=e2, am=am, v=v, mean_var=mean_var, merge=merge)
+        self.dmerge = None
+        if E.record:
+            dmerge = E.scratch(n * h * w)       # zero at step start; filled by the per-iteration closures
+            self.dmerge = dmerge
+
+            def bwd_bn():
+                red4, k2 = E.scratch(4), E.f32(2)
+                acc = E.grads.claim(e2, E)
+                L.check(E.lib.isa_maskbn_bwd(e2.d(), L.ptr(sem), L.ptr(dmerge), L.ptr(mean_var), P.ptr(pre + ".bn.weight"),
+                                             E.BN_EPS, L.ptr(am), train, L.ptr(red4), L.ptr(k2), P.gptr(pre + ".bn.weight"),
+                                             P.gptr(pre + ".bn.bias"), E.grads.grad_of(e2).d(), acc, E.st()),
+                        "isa_maskbn_bwd")
+            E.tape.append(bwd_bn)
         return merge
 
     # ------------------------------------------------------------------ pyramid decoder
@@ -149,7 +181,18 @@ class InstanceHead:
         if lvl > 0:
             up = E.new_act(n, h, w, out_ch)
             E.conv(x_prev, ua + ".up.weight", up, bias=ua + ".up.bias", transposed=True)
-            L.check(E.lib.isa_gate(up.d(), pred_prev.d(), cat.slice(0, out_ch).d(), None, E.st()), "isa_gate")
+            gated = cat.slice(0, out_ch)
+            gmap = E.f32(n * h * w) if E.record else None
+            L.check(E.lib.isa_gate(up.d(), pred_prev.d(), gated.d(), L.ptr(gmap), E.st()), "isa_gate")
+            if E.record:
+                def bwd_gate(up=up, pred_prev=pred_prev, gated=gated, gmap=gmap):
+                    du = E.scratch(n * h * w)
+                    acc_up = E.grads.claim(up, E)
+                    acc_pred = E.grads.claim(pred_prev, E)
+                    L.check(E.lib.isa_gate_bwd(E.grads.grad_of(gated).d(), up.d(), L.ptr(gmap), E.grads.grad_of(up).d(),
+                                               acc_up, L.ptr(du), E.grads.grad_of(pred_prev).d(), acc_pred, E.st()),
+                            "isa_gate_bwd")
+                E.tape.append(bwd_gate)
         aux = cat.slice(cross_off + ccross, naux)
         L.check(E.lib.isa_concat_aux(aux.d(), L.ptr(mask_all), L.ptr(s_t), W_full, f, nb, E.st()), "isa_concat_aux")
         if lvl == 0:
@@ -173,7 +216,7 @@ class InstanceHead:
         hmid = E.new_act(n, h, w, out_ch // 2)
         E.conv(x5, pre + ".pred.l_i.weight", hmid, taps=9, bias=pre + ".pred.l_i.bias")
         pred = E.new_act(n, h, w, 2)
-        E.conv(hmid.with_pro(Pro(act=L.ACT_LEAKY)), pre + ".pred.last_fc.1.weight", pred, taps=9,
+        E.conv(E.act(hmid, L.ACT_LEAKY), pre + ".pred.last_fc.1.weight", pred, taps=9,
                bias=pre + ".pred.last_fc.1.bias")
         return x5, pred
 
@@ -223,6 +266,9 @@ class InstanceHead:
         idx_dev = idx_host.to(E.device)
         skips = [feats[4], feats[3], feats[2], feats[1], feats[0]]
         iters = []
+        scal = E.scratch(4)          # {ins_cost (finite part), criterion, ins_ce_loss, ins_dice_loss}
+        if self.baseline is None:
+            self.baseline = torch.zeros(1, dtype=torch.float32, device=E.device)
         if capture is not None:
             capture.update(x_enc=x_enc, s_sp=s, merge=merge)
         for it in range(max_iter):
@@ -242,7 +288,9 @@ class InstanceHead:
                         "isa_pool_target")
                 targets.append(t)
             x, pred = None, None
-            preds, sums = [], []
+            preds = []
+            sums_all = E.scratch(5 * 8 * n)                 # [level][image][8], contiguous for isa_head_loss
+            sums = [sums_all[l * 8 * n:(l + 1) * 8 * n] for l in range(5)]
             for lvl in range(5):
                 masks = {}
                 if self.drop_rate > 0:
@@ -251,16 +299,28 @@ class InstanceHead:
                                  d2=self._drop_mask(n, oc, training))
                     masks = {k: v for k, v in masks.items() if v is not None}
                 x, pred = self.level(lvl, x, skips[lvl], pred, mask_all[lvl], s_t, W, training, masks)
-                sm = E.scratch(8 * n)
-                L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None, L.ptr(sm), E.st()),
+                L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None, L.ptr(sums[lvl]), E.st()),
                         "isa_mask_loss_sums")
                 preds.append(pred)
-                sums.append(sm)
                 if capture is not None:
                     capture["it%d.L%d.x" % (it, lvl)] = x
                     capture["it%d.L%d.pred" % (it, lvl)] = pred
+            coef, adv = E.f32(5 * 4 * n), E.f32(n)
+            L.check(E.lib.isa_head_loss(L.ptr(sums_all), L.ptr(alpha), L.ptr(s_t), Lp, n, self._level_w, CE_WEIGHT,
+                                        LAMBDA_L, LAMBDA_R, 1.0 / max_iter, L.ptr(self.baseline), 1 if training else 0,
+                                        L.ptr(coef), L.ptr(adv), L.ptr(scal), E.st()), "isa_head_loss")
+            if E.record:
+                def bwd_losses(preds=preds, targets=targets, coef=coef, alpha=alpha, idx=idx, s_t=s_t, adv=adv):
+                    for lvl in range(5):
+                        acc = E.grads.claim(preds[lvl], E)
+                        L.check(E.lib.isa_mask_loss_grad(preds[lvl].d(), L.ptr(targets[lvl]), None,
+                                                         L.ptr(coef[lvl * 4 * n:(lvl + 1) * 4 * n]),
+                                                         E.grads.grad_of(preds[lvl]).d(), acc, E.st()), "isa_mask_loss_grad")
+                    L.check(E.lib.isa_ins_softmax_bwd(L.ptr(alpha), L.ptr(ins), L.ptr(idx), L.ptr(s_t), L.ptr(adv), n, nobj,
+                                                      Lp, L.ptr(self.dmerge), E.st()), "isa_ins_softmax_bwd")
+                E.tape.append(bwd_losses)
             iters.append(dict(idx=idx, alpha=alpha, s_t=s_t, targets=targets, preds=preds, sums=sums))
-        return dict(iters=iters, max_iter=max_iter, merge=merge, x_enc=x_enc)
+        return dict(iters=iters, max_iter=max_iter, merge=merge, x_enc=x_enc, scal=scal)
 
     # ------------------------------------------------------------------ host-side scalar assembly
     @staticmethod

@@ -55,7 +55,7 @@ SIGNATURES = {
     "isa_avgpool2": [P_T, P_T, VP],
     "isa_avgpool2_bwd": [P_T, P_T, I32, VP],
     "isa_pool_f": [P_T, P_T, I32, I32, VP],
-    "isa_avgpool3": [P_T, P_T, P_T, VP],
+    "isa_avgpool3": [P_T, P_T, P_T, I32, VP],
     "isa_chan_mean": [P_T, P_PRO, VP, VP],
     "isa_se_fc": [VP, VP, VP, VP, VP, I32, I32, I32, VP, VP, VP],
     "isa_chan_argmax": [P_T, P_T, VP],
@@ -72,6 +72,18 @@ SIGNATURES = {
     "isa_concat_aux": [P_T, VP, VP, I32, I32, I32, VP],
     "isa_gate": [P_T, P_T, P_T, VP, VP],
     "isa_mask_loss_sums": [P_T, VP, VP, VP, VP],
+    "isa_head_loss": [VP, VP, VP, I64, I32, VP, F, F, F, F, VP, I32, VP, VP, VP, VP],
+    "isa_sem_loss": [VP, I32, VP, VP, VP],
+    "isa_mask_loss_grad": [P_T, VP, VP, VP, P_T, I32, VP],
+    "isa_ins_softmax_bwd": [VP, VP, VP, VP, VP, I32, I32, I64, VP, VP],
+    "isa_maskbn_bwd": [P_T, VP, VP, VP, VP, F, VP, I32, VP, VP, VP, VP, P_T, I32, VP],
+    "isa_sp_bwd": [P_T, P_T, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, F, I32, VP, P_T, I32,
+                   VP, VP, VP, VP, VP, VP, VP, VP],
+    "isa_gate_bwd": [P_T, P_T, VP, P_T, I32, VP, P_T, I32, VP],
+    "isa_se_bwd": [P_T, P_T, VP, VP, VP, VP, VP, I32, VP, VP, VP, VP, VP, VP, P_T, I32, VP],
+    "isa_scale_bc": [P_T, VP, P_T, I32, VP],
+    "isa_sqnorm": [VP, I64, F, VP, VP],
+    "isa_adadelta": [VP, VP, VP, VP, I64, F, F, F, F, VP, F, F, VP],
     "isa_nchw_to_nhwc": [VP, I32, P_T, VP],
     "isa_nhwc_to_nchw": [P_T, VP, VP],
 }

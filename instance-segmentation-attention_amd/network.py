@@ -104,9 +104,45 @@ class Network:
                                 L.ptr(hid), L.ptr(gate), E.st()), "isa_se_fc")
         gated = x_dec.with_pro(Pro(bscale=gate))
         sem = E.new_act(n, x_dec.h, x_dec.w, 2)
-        E.conv(gated, "sem_seg_output.weight", sem, bias="sem_seg_output.bias")
-        self._se_ctx = dict(mean=mean, hid=hid, gate=gate, x=x_dec, gated=gated)
+        E.conv(gated, "sem_seg_output.weight", sem, bias="sem_seg_output.bias", record_bwd=False)
+        reg = E._last_conv["reg"]
+        if E.record:
+            def bwd():
+                # sem conv: weight/bias grads see x*gate; its data gradient is w.r.t. x*gate (dxa)
+                dy = E.grads.grad_of(sem)
+                L.check(E.lib.isa_conv_wgrad(gated.d(), gated.p(), dy.d(), P.gptr("sem_seg_output.weight"),
+                                             P.gptr("sem_seg_output.bias"), L.IN_1X1, L.OUT_PLAIN, None, c, E.st()),
+                        "isa_conv_wgrad(sem)")
+                dxa = E.new_act(n, x_dec.h, x_dec.w, c)
+                L.check(E.lib.isa_conv_gemm(dy.d(), None, E.packer.ptr(reg["dgrad"]), reg["kp_d"], None, dxa.d(),
+                                            L.IN_1X1, L.OUT_PLAIN, None, 0, E.st()), "isa_conv_gemm(dgrad sem)")
+                dg, dmean = E.scratch(n * c), E.f32(n * c)
+                acc = E.grads.claim(x_dec, E)
+                L.check(E.lib.isa_se_bwd(dxa.d(), x_dec.d(), L.ptr(gate), L.ptr(hid), L.ptr(mean),
+                                         P.ptr("channelAttend.fc.0.weight"), P.ptr("channelAttend.fc.2.weight"), 16,
+                                         L.ptr(dg), L.ptr(dmean), P.gptr("channelAttend.fc.0.weight"),
+                                         P.gptr("channelAttend.fc.0.bias"), P.gptr("channelAttend.fc.2.weight"),
+                                         P.gptr("channelAttend.fc.2.bias"), E.grads.grad_of(x_dec).d(), acc, E.st()),
+                        "isa_se_bwd")
+            E.tape.append(bwd)
         return sem
+
+    def sem_loss(self, sem: Act, sem_onehot: torch.Tensor):
+        """Trainer-side CE + Dice(time=1) on the semantic logits (model.py:255-269).
+        Returns device tensor [ce, dice]; records d(sem)."""
+        E = self.E
+        n = sem.n
+        sums = E.scratch(8 * n)
+        L.check(E.lib.isa_mask_loss_sums(sem.d(), None, L.ptr(sem_onehot), L.ptr(sums), E.st()), "isa_mask_loss_sums")
+        coef, scal = E.f32(4 * n), E.f32(2)
+        L.check(E.lib.isa_sem_loss(L.ptr(sums), n, L.ptr(coef), L.ptr(scal), E.st()), "isa_sem_loss")
+        if E.record:
+            def bwd():
+                acc = E.grads.claim(sem, E)
+                L.check(E.lib.isa_mask_loss_grad(sem.d(), None, L.ptr(sem_onehot), L.ptr(coef),
+                                                 E.grads.grad_of(sem).d(), acc, E.st()), "isa_mask_loss_grad(sem)")
+            E.tape.append(bwd)
+        return scal
 
     def argmax_map(self, logits: Act):
         E = self.E

@@ -179,7 +179,6 @@ class ReSeg(nn.Module):
         rec = self.head.forward(x_dec, feats, sem_map, ins_dev, n_ins, bool(training), selected_idx,
                                 injected_s_t, capture)
         self.last_record = rec
-        sc = self.head.scalars_from_sums(rec, bool(training))
-        t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
-        return (sem_out, sem_argmax, t(sc["ins_cost"]), t(sc["criterion"]), t(sc["ins_ce_loss"]),
-                t(sc["ins_dice_loss"]))
+        scal = rec["scal"].clone()
+        ins_cost = scal[0] + float("nan") if training else scal[0]     # attenet2.py:77: H is NaN in training
+        return (sem_out, sem_argmax, ins_cost, scal[1], scal[2], scal[3])
