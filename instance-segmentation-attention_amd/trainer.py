@@ -10,6 +10,7 @@ import random
 import torch
 
 from . import lib as L
+from .parallel import allreduce_flat_
 
 
 class Trainer:
@@ -62,11 +63,7 @@ class Trainer:
     def apply_update(self):
         st = self.model.store
         n = st.n_train
-        gscale = 1.0
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(st.grad[:n])              # one flat RCCL all-reduce (sum), divided below
-            gscale = 1.0 / self.world
+        gscale = allreduce_flat_(st.grad, n, self.world)     # one flat RCCL all-reduce (sum)
         lib = self.model.engine.lib
         self.sqnorm.zero_()
         if self.clip > 0:
