@@ -115,7 +115,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
         const long m = (long)tile * 128 + wave * 32 + r;
         const bool mvalid = m < p.M;
         int pb = 0, py = 0, px = 0;
-        if (mvalid) { px = (int)(m % p.mw); long q = m / p.mw; py = (int)(q % p.mh); pb = (int)(q / p.mh); }
+        constexpr bool NEED_YX = IN_MODE != ISA_IN_1X1;
+        if (mvalid && (NEED_YX || (HAS_PRO && p.pro.bscale))) {     // 32-bit: M < 2^31 checked on the host
+            const unsigned mu = (unsigned)m, q = mu / (unsigned)p.mw;
+            px = (int)(mu - q * (unsigned)p.mw); pb = (int)(q / (unsigned)p.mh); py = (int)(q - (unsigned)pb * (unsigned)p.mh);
+        }
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
             } else if constexpr (IN_MODE == ISA_IN_GATHER2) {
                 sy = 2 * py + (tap >> 1); sx = 2 * px + (tap & 1);
             }
+            if constexpr (IN_MODE == ISA_IN_1X1) return xin + m * p.ldx + k;
             return xin + (((long)pb * p.xh + sy) * p.xw + sx) * p.ldx + k;
         };
 
@@ -233,8 +238,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
             if (mr < p.M && nseg < p.N) {
                 T* dst;
                 if constexpr (OUT_MODE == ISA_OUT_SHUFFLE2) {
-                    const int ox = (int)(mr % p.mw); const long q = mr / p.mw;
-                    const int oy = (int)(q % p.mh); const int ob = (int)(q / p.mh);
+                    const unsigned mu = (unsigned)mr, q = mu / (unsigned)p.mw;
+                    const int ox = (int)(mu - q * (unsigned)p.mw);
+                    const int ob = (int)(q / (unsigned)p.mh); const int oy = (int)(q - (unsigned)ob * (unsigned)p.mh);
                     const int quad = nseg / p.cout, co = nseg - quad * p.cout;
                     dst = reinterpret_cast<T*>(p.y) +
                           (((long)ob * p.oh + 2 * oy + (quad >> 1)) * p.ow + 2 * ox + (quad & 1)) * p.ldy + co;
@@ -360,6 +366,7 @@ extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void
         p.N = y->c; p.cout = y->c;
     }
     p.M = (long)x->n * p.mh * p.mw;
+    if (p.M >= (1L << 31)) return ISA_EINVAL;
     const bool has_pro = !pro_trivial(p.pro);
     if (x->dtype == ISA_BF16) return launch0<bf16_t>(p, has_pro, in_mode, out_mode, as_stream(stream));
     return launch0<float>(p, has_pro, in_mode, out_mode, as_stream(stream));

@@ -2,143 +2,259 @@
 // written straight into the reference's state_dict layout (fp32) with float atomics.
 //
 // The contraction runs over pixels, so for v_mfma_f32_32x32x2_f32 both operands are ROW reads of
-// the NHWC tiles: A[i=n][k'=pixel] -> lanes 0..31 read 32 consecutive channels of pixel 2s,
-// lanes 32..63 of pixel 2s+1 (and the same for B with the input channels).  No transpose, no
-// strided gathers.  Tiles are staged once per workgroup in LDS as fp32 (the lazy BN/ReLU6
-// prologue is applied there, once per element), then every wave feeds its 32x32 output tiles from
-// conflict-free ds_read_b32 rows.  bf16 storage converts to fp32 while staging: wgrad is <10 % of
-// step FLOPs at 1/16 MFMA rate vs. HBM time of the same tensors, so this stays memory-bound; the
-// bf16-MFMA + ds_read_b64_tr_b16 variant is listed in DESIGN.md as follow-up.
-//
-// Work split: blockIdx.x strides over 32-pixel chunks (split-M, combined by atomics),
-// blockIdx.y = (n-block, k-block) of <=128x128 outputs, blockIdx.z = tap.
+// NHWC tiles: A[i=n][k'=pixel] -> lanes 0..31 read 32 consecutive channels of pixel 2s, lanes 32..63
+// of pixel 2s+1 (same for B with the input channels): no transpose, no strided gathers.
+// v2 structure (gfx950):
+//   * every WAVE owns its own 16-pixel chunks: it stages dY[16][TN*32] and pro(X)[16][TK*32] as fp32
+//     in a wave-private LDS slab with 16-byte global loads (a lane = 8 channels of one pixel; the
+//     lazy BN/ReLU6 prologue is applied in registers, once per element), then feeds TN x TK output
+//     tiles from conflict-free ds_read_b32 rows.  No __syncthreads in the main loop, the next
+//     chunk's global loads are issued before the current chunk's MFMAs.
+//   * at the end the four waves of a workgroup add their accumulators in LDS and ONE wave issues the
+//     float atomics: 4x fewer atomics on the (small, hot) dW addresses.
+//   * blockIdx.x strides over chunks (split-M), blockIdx.y = (n-group, k-group) of <= 2x2 tiles,
+//     blockIdx.z = tap (3x3 dense / transposed-conv quadrant).
+// bf16 storage converts to fp32 while staging; exact-fp32 MFMA keeps weight gradients at fp32 accuracy
+// in both storage modes.  (bf16-MFMA + ds_read_b64_tr_b16 variant: DESIGN.md follow-ups.)
 #include "common.hpp"
 
 namespace {
 
-constexpr int PM = 32;          // pixels per staged chunk
-constexpr int TB = 128;         // max output rows/cols per block
+constexpr int PM = 16;          // pixels per wave-chunk (8 MFMA k-steps)
 
 struct WgParams {
-    const void* x; int xh, xw, cin, ldx;          // input image
-    const void* dy; int dh, dw_, cdy, ldd;        // output-gradient image
-    int mh, mw; long M;                           // M-grid (see conv_gemm)
+    const void* x; int xh, xw, cin, ldx;
+    const void* dy; int dh, dw_, ldd;
+    int mh, mw; long M;
     ProDev pro;
     float* dw; float* dbias;
-    const int32_t* kmap; int ksrc;                // physical->source channel map, source K
-    int N, taps, in_mode, out_mode, cout;
-    int nb_n, nb_k;                               // number of 128-blocks along N and K
-    int nchunks;
+    const int32_t* kmap; int ksrc;
+    int N, taps, in_mode, out_mode;
+    int groups_k;
+    long nchunks;
 };
 
 template <typename T>
+__device__ __forceinline__ void ldvec(const T* p, float (&v)[8], int nvalid) {
+    if (nvalid >= 8) load8<T>(p, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = i < nvalid ? st<T>::ld(p + i) : 0.f;
+    }
+}
+
+template <typename T, int TN, int TK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDN = TN * 32 + 4, LDK = TK * 32 + 4;      // +4 floats: rows stay 16-byte aligned
+    constexpr int SLAB = PM * (LDN + LDK);
+    constexpr int VN = TN * 4, VK = TK * 4;                  // 8-channel vectors per pixel row
+    constexpr int LOADS_N = PM * VN / 64, LOADS_K = PM * VK / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const int bn = blockIdx.y / p.nb_k, bk = blockIdx.y % p.nb_k;
+    const int gn = blockIdx.y / p.groups_k, gk = blockIdx.y % p.groups_k;
     const int tap = blockIdx.z;
-    const int n0 = bn * TB, k0 = bk * TB;
-    const int nb = min(TB, p.N - n0), kb = min(TB, p.cin - k0);     // valid extents
-    const int nt = (nb + 31) / 32, kt = (kb + 31) / 32;             // 32-tiles
-    const int ldn = nt * 32 + 1, ldk = kt * 32 + 1;                 // +1: rows land on distinct banks
-    float* sD = lds;                       // [PM][ldn]
-    float* sX = lds + PM * ldn;            // [PM][ldk]
-    const int ntiles = nt * kt;
-    f32x16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x16{0};
-    float dbsum = 0.f;                     // thread tid<nb accumulates column tid of dY
+    const int n0 = gn * TN * 32, k0 = gk * TK * 32;
+    float* sD = lds + wave * SLAB;
+    float* sX = sD + PM * LDN;
     const T* xin = reinterpret_cast<const T*>(p.x);
     const T* din = reinterpret_cast<const T*>(p.dy);
+    const bool plain = p.in_mode == ISA_IN_1X1 && p.out_mode == ISA_OUT_PLAIN;
 
-    for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
-        const long mbase = (long)chunk * PM;
-        __syncthreads();
-        // ---- stage dY rows: element (pix, n) for n in [n0, n0+nt*32) ------------------------
-        for (int i = tid; i < PM * nt * 32; i += 256) {
-            const int col = i % (nt * 32), pix = i / (nt * 32);
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = f32x16{0};
+    float dbs[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) dbs[i] = 0.f;
+
+    float rd[LOADS_N][8], rx[LOADS_K][8];
+
+    // global -> registers for one chunk (prologue applied to x here)
+    auto fetch = [&](long chunk) {
+        const long mbase = chunk * PM;
+#pragma unroll
+        for (int v = 0; v < LOADS_N; ++v) {
+            const int idx = v * 64 + lane, pix = idx / VN, c0 = n0 + (idx % VN) * 8;
             const long m = mbase + pix;
-            float v = 0.f;
-            if (m < p.M && col < nb) {
-                const int px = (int)(m % p.mw); const long q = m / p.mw;
-                const int py = (int)(q % p.mh); const int pb = (int)(q / p.mh);
-                int n = n0 + col; long off;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rd[v][j] = 0.f;
+            if (m < p.M && c0 < p.N) {
+                long row = m;
                 if (p.out_mode == ISA_OUT_SHUFFLE2) {
-                    // forward wrote column (tap q, co) to pixel (2y+dy,2x+dx); here tap == q
-                    off = (((long)pb * p.dh + 2 * py + (tap >> 1)) * p.dw_ + 2 * px + (tap & 1)) * p.ldd + n;
-                } else {
-                    off = m * p.ldd + n;
+                    const int px = (int)(m % p.mw); const long q = m / p.mw;
+                    const int py = (int)(q % p.mh); const long pb = q / p.mh;
+                    row = (pb * p.dh + 2 * py + (tap >> 1)) * p.dw_ + 2 * px + (tap & 1);
                 }
-                v = st<T>::ld(din + off);
+                ldvec<T>(din + row * p.ldd + c0, rd[v], p.N - c0);
             }
-            sD[pix * ldn + col] = v;
         }
-        // ---- stage X rows with the lazy prologue ---------------------------------------------
-        for (int i = tid; i < PM * kt * 32; i += 256) {
-            const int col = i % (kt * 32), pix = i / (kt * 32);
+#pragma unroll
+        for (int v = 0; v < LOADS_K; ++v) {
+            const int idx = v * 64 + lane, pix = idx / VK, c0 = k0 + (idx % VK) * 8;
             const long m = mbase + pix;
-            float v = 0.f;
-            if (m < p.M && col < kb) {
-                const int px = (int)(m % p.mw); const long q = m / p.mw;
-                const int py = (int)(q % p.mh); const int pb = (int)(q / p.mh);
-                int sy = py, sx = px; bool ok = true;
-                if (p.in_mode == ISA_IN_3X3) {
-                    sy = py + tap / 3 - 1; sx = px + tap % 3 - 1;
-                    ok = sy >= 0 && sy < p.xh && sx >= 0 && sx < p.xw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rx[v][j] = 0.f;
+            if (m < p.M && c0 < p.cin) {
+                long row = m; bool ok = true; long pb = 0;
+                if (!plain || p.pro.bscale) {
+                    const int px = (int)(m % p.mw); const long q = m / p.mw;
+                    const int py = (int)(q % p.mh); pb = q / p.mh;
+                    if (p.in_mode == ISA_IN_3X3) {
+                        const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
+                        ok = sy >= 0 && sy < p.xh && sx >= 0 && sx < p.xw;
+                        row = (pb * p.xh + sy) * p.xw + sx;
+                    }
                 }
                 if (ok) {
-                    const int k = k0 + col;
-                    v = st<T>::ld(xin + (((long)pb * p.xh + sy) * p.xw + sx) * p.ldx + k);
-                    if (p.pro.scale) v *= p.pro.scale[k];
-                    if (p.pro.shift) v += p.pro.shift[k];
-                    v = act_apply(v, p.pro.act);
-                    if (p.pro.bscale) v *= p.pro.bscale[(long)pb * p.cin + k];
+                    ldvec<T>(xin + row * p.ldx + c0, rx[v], p.cin - c0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = min(c0 + j, p.cin - 1);
+                        float z = rx[v][j];
+                        if (p.pro.scale) z *= p.pro.scale[c];
+                        if (p.pro.shift) z += p.pro.shift[c];
+                        z = act_apply(z, p.pro.act);
+                        if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + c];
+                        rx[v][j] = (c0 + j < p.cin) ? z : 0.f;
+                    }
                 }
             }
-            sX[pix * ldk + col] = v;
         }
-        __syncthreads();
-        if (p.dbias && bk == 0 && tap == 0 && tid < nb) {
-#pragma unroll 8
-            for (int pix = 0; pix < PM; ++pix) dbsum += sD[pix * ldn + tid];
+    };
+    auto stash = [&]() {          // registers -> wave-private LDS slab
+#pragma unroll
+        for (int v = 0; v < LOADS_N; ++v) {
+            const int idx = v * 64 + lane, pix = idx / VN, col = (idx % VN) * 8;
+            f32x4 a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = rd[v][j]; b[j] = rd[v][4 + j]; }
+            *reinterpret_cast<f32x4*>(sD + pix * LDN + col) = a;
+            *reinterpret_cast<f32x4*>(sD + pix * LDN + col + 4) = b;
         }
+#pragma unroll
+        for (int v = 0; v < LOADS_K; ++v) {
+            const int idx = v * 64 + lane, pix = idx / VK, col = (idx % VK) * 8;
+            f32x4 a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = rx[v][j]; b[j] = rx[v][4 + j]; }
+            *reinterpret_cast<f32x4*>(sX + pix * LDK + col) = a;
+            *reinterpret_cast<f32x4*>(sX + pix * LDK + col + 4) = b;
+        }
+    };
+
+    const long stride = (long)gridDim.x * 4;
+    long chunk = (long)blockIdx.x * 4 + wave;
+    if (chunk < p.nchunks) fetch(chunk);
+    for (; chunk < p.nchunks; chunk += stride) {
+        stash();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (chunk + stride < p.nchunks) fetch(chunk + stride);          // overlap with the MFMAs below
 #pragma unroll
         for (int s = 0; s < PM / 2; ++s) {
             const int row = 2 * s + hh;
+            float a[TN], b[TK];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = wave + 4 * i;
-                if (t < ntiles) {
-                    const int ni = t / kt, ki = t - ni * kt;
-                    const float a = sD[row * ldn + ni * 32 + r];
-                    const float b = sX[row * ldk + ki * 32 + r];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                }
+            for (int i = 0; i < TN; ++i) { a[i] = sD[row * LDN + i * 32 + r]; dbs[i] += a[i]; }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = sX[row * LDK + j * 32 + r];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- cross-wave reduction in LDS, then one atomic set per workgroup -----------------------
+    __syncthreads();
+    float* red = lds;                                   // [TN*TK*16*64] + [TN*32] (fits the 4 slabs)
+    constexpr int ACC_FLOATS = TN * TK * 16 * 64;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* q = red + ((i * TK + j) * 16 + e) * 64 + lane;
+                        *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
+                    }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const float s = dbs[i] + __shfl_xor(dbs[i], 32, 64);
+                if (hh == 0) { float* q = red + ACC_FLOATS + i * 32 + r; *q = (w == 0 ? 0.f : *q) + s; }
             }
         }
+        __syncthreads();
     }
-    // ---- epilogue: D[row = n][col = k] -> atomics into the reference layout -----------------
+    if (wave != 0) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = wave + 4 * i;
-        if (t >= ntiles) continue;
-        const int ni = t / kt, ki = t - ni * kt;
-        const int kd = k0 + ki * 32 + r;
-        if (kd >= p.cin) continue;
-        const int k = p.kmap ? p.kmap[kd] : kd;
-        if (k < 0) continue;
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = n0 + ni * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (n >= p.N) continue;
-            long off;
-            if (p.out_mode == ISA_OUT_SHUFFLE2) off = ((long)k * p.N + n) * 4 + tap;   // [K][Co][2][2]
-            else off = ((long)n * p.ksrc + k) * p.taps + tap;                          // [N][K][kh][kw]
-            atomicAdd(p.dw + off, acc[i][j]);
+        for (int j = 0; j < TK; ++j) {
+            const int kd = k0 + j * 32 + r;
+            if (kd >= p.cin) continue;
+            const int k = p.kmap ? p.kmap[kd] : kd;
+            if (k < 0) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (n >= p.N) continue;
+                const float v = red[((i * TK + j) * 16 + e) * 64 + lane];
+                long off;
+                if (p.out_mode == ISA_OUT_SHUFFLE2) off = ((long)k * p.N + n) * 4 + tap;   // [K][Co][2][2]
+                else off = ((long)n * p.ksrc + k) * p.taps + tap;                          // [N][K][kh][kw]
+                atomicAdd(p.dw + off, v);
+            }
+        }
+    if (p.dbias && gk == 0 && tap == 0 && hh == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + i * 32 + r;
+            if (n < p.N) atomicAdd(p.dbias + n, red[ACC_FLOATS + i * 32 + r]);
         }
     }
-    if (p.dbias && bk == 0 && tap == 0 && tid < nb) atomicAdd(p.dbias + n0 + tid, dbsum);
+}
+
+template <typename T, int TN, int TK>
+int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
+    constexpr int LDN = TN * 32 + 4, LDK = TK * 32 + 4;
+    const size_t slab = (size_t)PM * (LDN + LDK) * 4 * 4;
+    const size_t redb = ((size_t)TN * TK * 16 * 64 + TN * 32) * 4;
+    const size_t lds = slab > redb ? slab : redb;
+    const int gy = groups_n * p.groups_k;
+    long want = (p.nchunks + 3) / 4;
+    long cap = (256L * 2) / ((long)gy * p.taps);
+    if (cap < 1) cap = 1;
+    const int gx = (int)(want < cap ? want : cap);
+    dim3 grid(gx, gy, p.taps);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK>), grid, dim3(256), lds, s, p);
+    return launch_status();
+}
+
+template <typename T>
+int dispatch_wg(WgParams& p, hipStream_t s) {
+    const int nt = (p.N + 31) / 32, kt = (p.cin + 31) / 32;
+    int tn, tk;                         // tiles per wave: up to 4 accumulators (64 VGPRs)
+    if (nt == 1) { tn = 1; tk = kt >= 4 ? 4 : (kt >= 2 ? 2 : 1); }
+    else if (kt == 1) { tk = 1; tn = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1); }
+    else { tn = 2; tk = 2; }
+    const int groups_n = (nt + tn - 1) / tn;
+    p.groups_k = (kt + tk - 1) / tk;
+    if (tn == 1 && tk == 1) return launch_wg<T, 1, 1>(p, groups_n, s);
+    if (tn == 1 && tk == 2) return launch_wg<T, 1, 2>(p, groups_n, s);
+    if (tn == 2 && tk == 1) return launch_wg<T, 2, 1>(p, groups_n, s);
+    if (tn == 2 && tk == 2) return launch_wg<T, 2, 2>(p, groups_n, s);
+    if (tn == 1 && tk == 4) return launch_wg<T, 1, 4>(p, groups_n, s);
+    if (tn == 4 && tk == 1) return launch_wg<T, 4, 1>(p, groups_n, s);
+    return ISA_EINVAL;
 }
 
 }  // namespace
@@ -146,39 +262,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                               float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
                               const int32_t* kmap, int32_t ksrc, void* stream) {
-    if (!tensor_ok(x, 1) || !tensor_ok(dy, 1) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
+    if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (in_mode == ISA_IN_GATHER2) return ISA_EINVAL;
     WgParams p{};
     p.x = x->data; p.xh = x->h; p.xw = x->w; p.cin = x->c; p.ldx = x->ld;
-    p.dy = dy->data; p.dh = dy->h; p.dw_ = dy->w; p.cdy = dy->c; p.ldd = dy->ld;
+    p.dy = dy->data; p.dh = dy->h; p.dw_ = dy->w; p.ldd = dy->ld;
     p.mh = x->h; p.mw = x->w; p.M = (long)x->n * x->h * x->w;
     p.pro = make_pro(pro); p.dw = dw; p.dbias = dbias; p.kmap = kmap; p.ksrc = ksrc > 0 ? ksrc : x->c;
     p.in_mode = in_mode; p.out_mode = out_mode;
     if (out_mode == ISA_OUT_SHUFFLE2) {
         if (in_mode != ISA_IN_1X1 || dy->h != 2 * x->h || dy->w != 2 * x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = 4; p.N = dy->c;
-        // dbias of a transposed conv sums over all four quadrants: handled by the caller via
-        // isa_colsum on dy (kept out of this kernel so tap blocks stay independent)
-        if (dbias) return ISA_EINVAL;
+        if (dbias) return ISA_EINVAL;       // bias of a transposed conv sums all quadrants: isa_colsum
     } else {
         if (dy->h != x->h || dy->w != x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = in_mode == ISA_IN_3X3 ? 9 : 1; p.N = dy->c;
     }
-    p.cout = dy->c;
-    p.nb_n = (p.N + TB - 1) / TB; p.nb_k = (p.cin + TB - 1) / TB;
-    p.nchunks = (int)((p.M + PM - 1) / PM);
-    const int tiles_yz = p.nb_n * p.nb_k * p.taps;
-    int gx = p.nchunks;
-    const int cap = max(1, 1024 / tiles_yz);
-    if (gx > cap) gx = cap;
-    dim3 grid(gx, p.nb_n * p.nb_k, p.taps);
-    const int mx = min(TB, ((p.N + 31) / 32) * 32), kx = min(TB, ((p.cin + 31) / 32) * 32);
-    const size_t lds = (size_t)PM * ((mx + 1) + (kx + 1)) * 4;
-    if (x->dtype == ISA_BF16)
-        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, as_stream(stream), p);
-    else
-        hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, as_stream(stream), p);
-    return launch_status();
+    p.nchunks = (p.M + PM - 1) / PM;
+    if (x->dtype == ISA_BF16) return dispatch_wg<bf16_t>(p, as_stream(stream));
+    return dispatch_wg<float>(p, as_stream(stream));
 }
 
 // column sums of an NHWC view: out[c] += sum over pixels (bias gradients of transposed convs, heads)
@@ -188,7 +290,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long pixels, in
     extern __shared__ float red[];
     for (int i = threadIdx.x; i < c; i += 256) red[i] = 0.f;
     __syncthreads();
-    // thread -> channel (tid % c) when c <= 256, rows strided
     const int lanes_c = c < 256 ? c : 256;
     const int rows_per_pass = 256 / lanes_c;
     const int ch = threadIdx.x % lanes_c, rsub = threadIdx.x / lanes_c;

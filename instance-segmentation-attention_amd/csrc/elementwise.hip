@@ -95,9 +95,22 @@ struct BnBwdParams {
     long pixels; int cg;
 };
 
+// Division-free walk over (pixel, 8-channel group): a workgroup is laid out as
+// [256 >> sh pixels] x [1 << sh channel groups] (sh = ceil log2 of the group count), so a lane keeps
+// ONE channel group for its whole life: per-channel constants and partial sums live in registers,
+// addresses advance by adds only (64-bit integer division costs ~100 instructions on CDNA).
+struct Walk { int cg, sh; long pixels; };
+static inline Walk mkwalk(int c, long pixels) {
+    Walk w; w.cg = (c + 7) / 8; w.sh = 0;
+    while ((1 << w.sh) < w.cg) ++w.sh;
+    if (w.sh > 8) w.sh = 8;
+    w.pixels = pixels; return w;
+}
+static inline int walk_grid(const Walk& w) { return grid_cap(cdiv(w.pixels, 256 >> w.sh)); }
+
 // z = scale*y+shift ; dz = dt * bscale * act'(z)
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
     extern __shared__ float red[];              // reduce pass: [2*C]
     const int C = p.y.c;
     if (!APPLY) {
@@ -109,64 +122,48 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
             if (p.dbeta) atomicAdd(p.dbeta + i, p.red[i]);
         }
     }
-    // threads of a block share the channel group pattern: item = pixel*cg + cgi
-    const long items = p.pixels * p.cg;
-    const long stride = (long)gridDim.x * 256;
-    // stride is a multiple of cg when 256 % cg == 0; otherwise recompute cgi per item
-    float s0[8], s1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
-    int last_c0 = -1;
-    float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
-    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += stride) {
-        const int cgi = (int)(item % p.cg);
-        const long pix = item / p.cg;
+    const int ppb = 256 >> wk.sh;
+    const int psub = threadIdx.x >> wk.sh;
+    const unsigned hw = (unsigned)p.y.h * (unsigned)p.y.w;
+    for (int cgi = threadIdx.x & ((1 << wk.sh) - 1); cgi < wk.cg; cgi += (1 << wk.sh)) {
         const int c0 = cgi * 8;
-        if (c0 != last_c0) {
-            if (!APPLY && last_c0 >= 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (last_c0 + j < C) { atomicAdd(&red[last_c0 + j], s0[j]); atomicAdd(&red[C + last_c0 + j], s1[j]); }
-                    s0[j] = 0.f; s1[j] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = min(c0 + j, C - 1);
-                sc[j] = p.scale ? p.scale[c] : 1.f;
-                sh[j] = p.shift ? p.shift[c] : 0.f;
-                mu[j] = p.mean ? p.mean[c] : 0.f;
-                is[j] = p.invstd ? p.invstd[c] : 1.f;
-                if (APPLY) {
-                    k0[j] = p.train ? p.red[c] * p.inv_count : 0.f;
-                    k1[j] = p.train ? p.red[C + c] * p.inv_count : 0.f;
-                }
-            }
-            last_c0 = c0;
-        }
-        const int b = (int)(pix / ((long)p.y.h * p.y.w));
-        float dt[8], yv[8];
         const int nv = min(8, C - c0);
-        load8g<T>(reinterpret_cast<const T*>(p.dt.data) + pix * p.dt.ld + c0, dt, nv);
-        load8g<T>(reinterpret_cast<const T*>(p.y.data) + pix * p.y.ld + c0, yv, nv);
-        float out[8];
+        float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], s0[8], s1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float z = fmaf(yv[j], sc[j], sh[j]);
-            float dz = dt[j] * act_grad(z, p.act);
-            if (p.bscale) dz *= p.bscale[(long)b * C + min(c0 + j, C - 1)];
-            const float yh = (yv[j] - mu[j]) * is[j];
-            if (!APPLY) { s0[j] += dz; s1[j] += dz * yh; }
-            else out[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
+            const int c = min(c0 + j, C - 1);
+            sc[j] = p.scale ? p.scale[c] : 1.f;
+            sh[j] = p.shift ? p.shift[c] : 0.f;
+            mu[j] = p.mean ? p.mean[c] : 0.f;
+            is[j] = p.invstd ? p.invstd[c] : 1.f;
+            k0[j] = (APPLY && p.train) ? p.red[c] * p.inv_count : 0.f;
+            k1[j] = (APPLY && p.train) ? p.red[C + c] * p.inv_count : 0.f;
+            s0[j] = 0.f; s1[j] = 0.f;
         }
-        if (APPLY) store8g<T>(reinterpret_cast<T*>(p.dy.data) + pix * p.dy.ld + c0, out, nv);
-    }
-    if (!APPLY) {
-        if (last_c0 >= 0) {
+        const long step = (long)gridDim.x * ppb;
+        for (long pix = (long)blockIdx.x * ppb + psub; pix < wk.pixels; pix += step) {
+            float dt[8], yv[8], out[8];
+            load8g<T>(reinterpret_cast<const T*>(p.dt.data) + pix * p.dt.ld + c0, dt, nv);
+            load8g<T>(reinterpret_cast<const T*>(p.y.data) + pix * p.y.ld + c0, yv, nv);
+            const float* bs = p.bscale ? p.bscale + (long)((unsigned)pix / hw) * C : nullptr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float z = fmaf(yv[j], sc[j], sh[j]);
+                float dz = dt[j] * act_grad(z, p.act);
+                if (bs) dz *= bs[min(c0 + j, C - 1)];
+                const float yh = (yv[j] - mu[j]) * is[j];
+                if (!APPLY) { s0[j] += dz; s1[j] += dz * yh; }
+                else out[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
+            }
+            if (APPLY) store8g<T>(reinterpret_cast<T*>(p.dy.data) + pix * p.dy.ld + c0, out, nv);
+        }
+        if (!APPLY) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (last_c0 + j < C) { atomicAdd(&red[last_c0 + j], s0[j]); atomicAdd(&red[C + last_c0 + j], s1[j]); }
+                if (j < nv) { atomicAdd(&red[c0 + j], s0[j]); atomicAdd(&red[C + c0 + j], s1[j]); }
         }
+    }
+    if (!APPLY) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * C; i += 256)
             if (red[i] != 0.f) atomicAdd(p.out_red + i, red[i]);
@@ -176,43 +173,51 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
 // out = (pro(x) (+ res) (+ res2)) * oscale[b,c]
 struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; };
 template <typename T>
-__global__ __launch_bounds__(256) void materialize_kernel(MatParams p) {
-    const long items = p.pixels * p.cg;
+__global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) {
     const int C = p.x.c;
-    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long)gridDim.x * 256) {
-        const int c0 = (int)(item % p.cg) * 8;
-        const long pix = item / p.cg;
-        const int b = (int)(pix / ((long)p.x.h * p.x.w));
-        float v[8];
+    const int ppb = 256 >> wk.sh;
+    const int psub = threadIdx.x >> wk.sh;
+    const unsigned hw = (unsigned)p.x.h * (unsigned)p.x.w;
+    for (int cgi = threadIdx.x & ((1 << wk.sh) - 1); cgi < wk.cg; cgi += (1 << wk.sh)) {
+        const int c0 = cgi * 8;
         const int nv = min(8, C - c0);
-        load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, v, nv);
+        float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = min(c0 + j, C - 1);
-            float z = v[j];
-            if (p.pro.scale) z *= p.pro.scale[c];
-            if (p.pro.shift) z += p.pro.shift[c];
-            z = act_apply(z, p.pro.act);
-            if (p.pro.bscale) z *= p.pro.bscale[(long)b * C + c];
-            v[j] = z;
+            sc[j] = p.pro.scale ? p.pro.scale[c] : 1.f;
+            sh[j] = p.pro.shift ? p.pro.shift[c] : 0.f;
         }
-        if (p.has_res) {
-            float rr[8];
-            load8g<T>(reinterpret_cast<const T*>(p.res.data) + pix * p.res.ld + c0, rr, nv);
+        const bool per_image = p.pro.bscale || p.oscale;
+        const long step = (long)gridDim.x * ppb;
+        for (long pix = (long)blockIdx.x * ppb + psub; pix < wk.pixels; pix += step) {
+            float v[8];
+            load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, v, nv);
+            const long bofs = per_image ? (long)((unsigned)pix / hw) * C : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += rr[j];
-        }
-        if (p.has_res2) {
-            float rr[8];
-            load8g<T>(reinterpret_cast<const T*>(p.res2.data) + pix * p.res2.ld + c0, rr, nv);
+            for (int j = 0; j < 8; ++j) {
+                float z = act_apply(fmaf(v[j], sc[j], sh[j]), p.pro.act);
+                if (p.pro.bscale) z *= p.pro.bscale[bofs + min(c0 + j, C - 1)];
+                v[j] = z;
+            }
+            if (p.has_res) {
+                float rr[8];
+                load8g<T>(reinterpret_cast<const T*>(p.res.data) + pix * p.res.ld + c0, rr, nv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += rr[j];
-        }
-        if (p.oscale) {
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+            if (p.has_res2) {
+                float rr[8];
+                load8g<T>(reinterpret_cast<const T*>(p.res2.data) + pix * p.res2.ld + c0, rr, nv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= p.oscale[(long)b * C + min(c0 + j, C - 1)];
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+            if (p.oscale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= p.oscale[bofs + min(c0 + j, C - 1)];
+            }
+            store8g<T>(reinterpret_cast<T*>(p.out.data) + pix * p.out.ld + c0, v, nv);
         }
-        store8g<T>(reinterpret_cast<T*>(p.out.data) + pix * p.out.ld + c0, v, nv);
     }
 }
 
@@ -223,7 +228,8 @@ __global__ __launch_bounds__(256) void axpy_kernel(AxpyParams p) {
     const long items = p.pixels * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C); const long pix = i / C;
-        float v = p.alpha * st<T>::ld(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c);
+        // alpha == 0 is a FILL: never touch src (0 * uninitialised NaN would poison the destination)
+        float v = p.alpha == 0.f ? 0.f : p.alpha * st<T>::ld(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c);
         T* d = reinterpret_cast<T*>(p.dst.data) + pix * p.dst.ld + c;
         if (p.accumulate) v += st<T>::ld(d);
         st<T>::stv(d, v);
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(256) void axpy8_kernel(AxpyParams p) {
     const long items = p.pixels * cg;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * 8; const long pix = i / cg;
-        float v[8];
-        load8<T>(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c0, v);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.alpha != 0.f) load8<T>(reinterpret_cast<const T*>(p.src.data) + pix * p.src.ld + c0, v);
         T* d = reinterpret_cast<T*>(p.dst.data) + pix * p.dst.ld + c0;
         if (p.accumulate) {
             float o[8]; load8<T>(d, o);
@@ -469,16 +475,18 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     p.dt = mkview(dt); p.y = mkview(y);
     if (apply) { if (!tensor_ok(dy, 8) || !same_shape(dy, y)) return ISA_EINVAL; p.dy = mkview(dy); }
     p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
-    const int grid = grid_cap(cdiv(p.pixels * p.cg, 256));
+    if (p.pixels >= (1L << 32)) return ISA_EINVAL;
+    const Walk wk = mkwalk(y->c, p.pixels);
+    const int grid = walk_grid(wk);
     const size_t lds = apply ? 0 : 2 * (size_t)y->c * 4;
     if (apply)
         DISPATCH_T(y->dtype,
-            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), lds, as_stream(stream), p),
-            hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(256), lds, as_stream(stream), p));
+            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk));
     else
         DISPATCH_T(y->dtype,
-            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), lds, as_stream(stream), p),
-            hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(256), lds, as_stream(stream), p));
+            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk));
     return launch_status();
 }
 
@@ -517,10 +525,12 @@ extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const
     if (res) p.res = mkview(res);
     if (res2) p.res2 = mkview(res2);
     p.pixels = (long)x->n * x->h * x->w; p.cg = (x->c + 7) / 8;
-    const int grid = grid_cap(cdiv(p.pixels * p.cg, 256));
+    if (p.pixels >= (1L << 32)) return ISA_EINVAL;
+    const Walk wk = mkwalk(x->c, p.pixels);
+    const int grid = walk_grid(wk);
     DISPATCH_T(x->dtype,
-        hipLaunchKernelGGL(materialize_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),
-        hipLaunchKernelGGL(materialize_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p));
+        hipLaunchKernelGGL(materialize_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
+        hipLaunchKernelGGL(materialize_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
     return launch_status();
 }
 

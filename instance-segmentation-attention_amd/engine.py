@@ -459,6 +459,8 @@ class Engine:
                     if bias is not None:
                         L.check(self.lib.isa_colsum(dy.d(), self.params.gptr(bias), self.st()), "isa_colsum")
                 else:
+                    if self.profile:
+                        self.next_bytes = (x.n * x.h * x.w * x.c + dy.n * dy.h * dy.w * dy.c) * x.buf.element_size()
                     L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                     self.params.gptr(bias) if bias else None, in_mode,
                                                     L.OUT_PLAIN, pk.kmap_ptr(reg["fwd"]),

@@ -1,0 +1,65 @@
+"""Kernel micro-benchmarks at the shapes that dominate the train step (event-timed, L2-cold-ish)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import torch
+import isa_amd  # noqa
+from isa_amd import lib as L
+from isa_amd.engine import Act, Engine, ParamStore, Pro
+
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3   # us
+
+def rnd(n, h, w, c, dtype):
+    return Act(torch.randn(n, h, w, (c + 7) // 8 * 8, device="cuda").to(dtype), 0, c)
+
+def main(dtype=torch.bfloat16, which=None):
+    esz = 2 if dtype == torch.bfloat16 else 4
+    B = 16
+    rows = []
+    shapes = [(256, 32), (256, 64), (128, 128), (64, 256), (16, 1024)]
+    for hw, c in shapes:
+        schema = [("w", (c, c, 1, 1)), ("wd", (c, 1, 3, 3)), ("bn.weight", (c,)), ("bn.bias", (c,)),
+                  ("bn.running_mean", (c,)), ("bn.running_var", (c,)), ("bn.num_batches_tracked", ())]
+        ps = ParamStore(schema, "cuda")
+        ps.load_state_dict({"w": torch.randn(c, c, 1, 1) * c ** -0.5, "wd": torch.randn(c, 1, 3, 3) / 3,
+                            "bn.weight": torch.ones(c), "bn.bias": torch.zeros(c), "bn.running_mean": torch.zeros(c),
+                            "bn.running_var": torch.ones(c)})
+        eng = Engine(ps, dtype)
+        eng.begin(True, False)
+        x, y, dy = rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype)
+        sc, sh = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda")
+        xl = x.with_pro(Pro(sc, sh, L.ACT_RELU6))
+        nbytes = B * hw * hw * c * esz
+        st = torch.zeros(2 * c, device="cuda")
+        mean, inv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        red = torch.zeros(2 * c, device="cuda")
+        reg = eng.reg_conv("w"); regd = eng.reg_dw("wd"); eng.packer.pack()
+        lib = eng.lib
+        tests = {
+            "conv1x1": (lambda: lib.isa_conv_gemm(x.d(), None, eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
+            "conv1x1+pro": (lambda: lib.isa_conv_gemm(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
+            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.stream_ptr()), 2),
+            "dw+pro": (lambda: lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(regd["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), 2),
+            "dw_dgrad": (lambda: lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(regd["dgrad"]), y.d(), 0, L.stream_ptr()), 2),
+            "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.stream_ptr()), 2),
+            "bn_bwd_reduce": (lambda: lib.isa_bn_bwd_reduce(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, L.ptr(red), L.stream_ptr()), 2),
+            "bn_bwd_apply": (lambda: lib.isa_bn_bwd_apply(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, ps.ptr("bn.weight"), L.ptr(red), float(B * hw * hw), 1, y.d(), None, None, L.stream_ptr()), 3),
+            "materialize+res": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), dy.d(), None, None, y.d(), L.stream_ptr()), 3),
+        }
+        for name, (fn, ntens) in tests.items():
+            if which and which not in name: continue
+            us = timeit(fn)
+            rows.append((name, hw, c, us, ntens * nbytes / us / 1e3))
+    print("%-18s %5s %5s %10s %10s" % ("kernel", "hw", "c", "us", "GB/s(alg)"))
+    for r in sorted(rows):
+        print("%-18s %5d %5d %10.1f %10.0f" % r)
+
+if __name__ == "__main__":
+    main(torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] != "f32") else torch.float32, sys.argv[2] if len(sys.argv) > 2 else None)

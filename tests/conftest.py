@@ -18,3 +18,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def poison_gpu_allocator():
+    """Fill several GiB of device memory with NaN and hand it back to torch's caching allocator, so
+    every later `torch.empty` in the engine's arena starts as NaN: any kernel that reads memory it
+    was supposed to overwrite first (or computes 0*garbage) turns the parity tests red."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            junk = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(8)]
+            del junk
+    except Exception:
+        pass
+    yield
