@@ -27,6 +27,7 @@ extern "C" {
 
 enum { ISA_F32 = 0, ISA_BF16 = 1 };
 enum { ISA_ACT_NONE = 0, ISA_ACT_RELU = 1, ISA_ACT_RELU6 = 2, ISA_ACT_LEAKY = 3, ISA_ACT_TANH = 4 };
+enum { ISA_STAT_REPLICAS = 8 };   /* layout of every per-channel statistics buffer: [8][2*C] */
 enum { ISA_OK = 0, ISA_EINVAL = -1, ISA_EALIGN = -2, ISA_EDTYPE = -3, ISA_ELAUNCH = -4 };
 
 /* conv_gemm input addressing */
@@ -83,8 +84,9 @@ int isa_pack_weights(const isa_pack_entry* table_dev, int32_t n_entries, const i
  * nn.ConvTranspose2d(k=2,s=2) forward and their data-gradients (MobileNetDenseASPP.py:68-123 1x1
  * convs, utils.py:703-707 L0Layer, unet_parts.py:73 / utils.py:975 up-convs, reseg.py:73 head).
  * w: packed weights from isa_pack_weights ([Nrows][taps][kp], dtype = x.dtype).
- * stats: optional float[2*N]; per-channel sum and sum of squares of the fp32 result are atomically
- *        added (train-mode BatchNorm statistics fused into the producer).
+ * stats: optional float[ISA_STAT_R][2*N] (zeroed by the caller); per-channel sum and sum of squares of
+ *        the fp32 result are atomically added into replica (workgroup & 7): train-mode BatchNorm
+ *        statistics fused into the producer without serialising on a handful of L2 atomics.
  * accumulate != 0: y += result (gradient accumulation for multi-consumer tensors).            */
 int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
                   const float* bias, const isa_tensor* y, int32_t in_mode, int32_t out_mode,

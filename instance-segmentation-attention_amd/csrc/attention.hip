@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void scaled_stats_kernel(View x, const float* 
             if (last + j < C) { atomicAdd(&red[last + j], s0[j]); atomicAdd(&red[C + last + j], s1[j]); }
     }
     __syncthreads();
+    float* rep = stats + (blockIdx.x & (ISA_STAT_R - 1)) * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += 256)
-        if (red[i] != 0.f) atomicAdd(stats + i, red[i]);
+        if (red[i] != 0.f) atomicAdd(rep + i, red[i]);
 }
 
 // ---- a7 step 4: out = x + (scale*x*beta + shift) * m -------------------------------------------

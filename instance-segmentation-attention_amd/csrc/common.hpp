@@ -12,6 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ISA_WAVE 64
+// per-channel statistics are accumulated into ISA_STAT_R replicas ([R][2C], replica = workgroup & 7)
+// so that thousands of workgroups do not serialise on the same few L2 atomic addresses; consumers
+// (isa_bn_finalize, isa_bn_bwd_apply) sum the replicas.
+#define ISA_STAT_R 8
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -103,6 +107,20 @@ __device__ __forceinline__ float act_grad(float z, int act) {
         case ISA_ACT_TANH:  { float t = tanhf(z); return 1.f - t * t; }
         default:            return 1.f;
     }
+}
+
+// compile-time activation: ACT = ISA_ACT_RELU6 / ISA_ACT_NONE are specialised (branch-free inner loops),
+// ACT = -1 takes the runtime switch.  Hot kernels are instantiated for {RELU6, runtime}.
+constexpr int ACT_RT = -1;
+template <int ACT> __device__ __forceinline__ float act_t(float z, int rt) {
+    if constexpr (ACT == ISA_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
+    else if constexpr (ACT == ISA_ACT_NONE) return z;
+    else return act_apply(z, rt);
+}
+template <int ACT> __device__ __forceinline__ float act_grad_t(float z, int rt) {
+    if constexpr (ACT == ISA_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+    else if constexpr (ACT == ISA_ACT_NONE) return 1.f;
+    else return act_grad(z, rt);
 }
 
 // device-side copy of isa_pro with nulls normalised

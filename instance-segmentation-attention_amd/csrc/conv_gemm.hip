@@ -76,10 +76,12 @@ __device__ __forceinline__ void frag_set(Frag<T>& f, int j, float x) {
     f.v[j / V][j % V] = (T)x;
 }
 
-template <typename T, int NT, int IN_MODE, int OUT_MODE, bool HAS_PRO>
+template <typename T, int NT, int IN_MODE, int OUT_MODE, int PRO>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N_BLK = 32 * NT;
+    constexpr bool HAS_PRO = PRO != 0;
+    constexpr int ACT = PRO == 1 ? ISA_ACT_RELU6 : ACT_RT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int n0 = blockIdx.y * N_BLK;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                         for (int j = 0; j < 16; ++j) {
                             const int k = kcur + j;
                             float v = frag_get<T>(cur, j);
-                            v = act_apply(fmaf(v, pro_tab[k], pro_tab[p.kp + k]), p.pro.act);
+                            v = act_t<ACT>(fmaf(v, pro_tab[k], pro_tab[p.kp + k]), p.pro.act);
                             if (p.pro.bscale) v *= (k < p.cin) ? p.pro.bscale[(long)pb * p.cin + k] : 0.f;
                             if (k >= p.cin) v = 0.f;
                             frag_set<T>(cur, j, v);
@@ -282,8 +284,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
         for (int t = 0; t < NT; ++t) {
             const int n = n0 + t * 32 + r;
             if (hh == 0 && n < p.N) {
-                atomicAdd(p.stats + n, st_sum[t]);
-                atomicAdd(p.stats + p.N + n, st_sq[t]);
+                float* rep = p.stats + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.N;
+                atomicAdd(rep + n, st_sum[t]);
+                atomicAdd(rep + p.N + n, st_sq[t]);
             }
         }
     }
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 
 template <typename T, int NT, int IN_MODE, int OUT_MODE>
 int launch2(const GemmParams& p, bool has_pro, dim3 grid, size_t lds, hipStream_t s) {
-    if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, false>), grid, dim3(256), lds, s, p);
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1>), grid, dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 2>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 0>), grid, dim3(256), lds, s, p);
     return launch_status();
 }
 
@@ -325,7 +329,7 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     p.ntiles = (int)((p.M + 127) / 128);
     const int gy = (p.N + n_blk - 1) / n_blk;
     int gx = p.ntiles;
-    const int cap = max(1, (256 * 3) / gy);
+    const int cap = max(1, (256 * 2) / gy);
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
     switch (nt) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void ldvec(const T* p, float (&v)[8], int nvalid) {
     }
 }
 
-template <typename T, int TN, int TK>
+template <typename T, int TN, int TK, int ACT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDN = TN * 32 + 4, LDK = TK * 32 + 4;      // +4 floats: rows stay 16-byte aligned
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
                         float z = rx[v][j];
                         if (p.pro.scale) z *= p.pro.scale[c];
                         if (p.pro.shift) z += p.pro.shift[c];
-                        z = act_apply(z, p.pro.act);
+                        z = act_t<ACT>(z, p.pro.act);
                         if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + c];
                         rx[v][j] = (c0 + j < p.cin) ? z : 0.f;
                     }
@@ -235,7 +235,9 @@ int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
     if (cap < 1) cap = 1;
     const int gx = (int)(want < cap ? want : cap);
     dim3 grid(gx, gy, p.taps);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK>), grid, dim3(256), lds, s, p);
+    if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
+    else if (p.pro.act == ISA_ACT_NONE) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ACT_RT>), grid, dim3(256), lds, s, p);
     return launch_status();
 }
 

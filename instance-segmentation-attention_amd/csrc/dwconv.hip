@@ -56,7 +56,7 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[CH], int nv) {
     }
 }
 
-template <typename T, int CH, bool HAS_PRO>
+template <typename T, int CH, bool HAS_PRO, int ACT>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwParams p) {
     extern __shared__ float red[];        // [2*C] when stats
     if (p.stats) {
@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwParams p) {
                     loadv<T, CH>(xin + (((long)b * p.h + yy) * p.w_ + xc) * p.ldx + c0, v, nv);
                     if constexpr (HAS_PRO) {
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) v[j] = act_apply(fmaf(v[j], sc[j], sh[j]), p.pro.act) * bs[j];
+                        for (int j = 0; j < CH; ++j) v[j] = act_t<ACT>(fmaf(v[j], sc[j], sh[j]), p.pro.act);
+                        if (p.pro.bscale) {
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) v[j] *= bs[j];
+                        }
                     }
                     // input (yy,xc) feeds output (y, xc+1-tx) through tap (dy, tx)
 #pragma unroll
@@ -148,8 +152,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwParams p) {
             }
         }
         __syncthreads();
+        float* rep = p.stats + (blockIdx.x & (ISA_STAT_R - 1)) * 2 * p.c;
         for (int i = threadIdx.x; i < 2 * p.c; i += 256)
-            if (red[i] != 0.f) atomicAdd(p.stats + i, red[i]);
+            if (red[i] != 0.f) atomicAdd(rep + i, red[i]);
     }
 }
 
@@ -157,32 +162,33 @@ struct DwWgParams {
     const void* x; const void* dy; float* dw; float* dbias;
     int n, h, w_, c, ldx, ldd;
     ProDev pro;
-    long items; int nstrips, cg; int csrc;
+    long items; int nstrips, cg; int csrc; int cg_pad;
 };
 
 // dw[c][t] (reference [C,1,3,3] layout) += sum_p dy[p,c] * xt[p + off(t), c];  dbias[c] += sum_p dy[p,c]
-template <typename T, int CH, bool HAS_PRO>
+// Persistent: at most 512 workgroups; a lane keeps ONE channel group for its whole life (items are
+// laid out strip-major, channel-group-minor and the grid stride is a multiple of the group count), walks
+// many row strips accumulating its 9x8 products in registers and flushes once (LDS, then one global
+// atomic per (tap, channel) per workgroup).
+template <typename T, int CH, bool HAS_PRO, int ACT>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgParams p) {
     extern __shared__ float red[];        // [10*C]
     for (int i = threadIdx.x; i < 10 * p.c; i += 256) red[i] = 0.f;
     __syncthreads();
-    const long item = (long)blockIdx.x * 256 + threadIdx.x;
-    if (item < p.items) {
-        const int cgi = (int)(item % p.cg); long q = item / p.cg;
-        const int s = (int)(q % p.nstrips); q /= p.nstrips;
-        const int y = (int)(q % p.h); const int b = (int)(q / p.h);
+    const int cg_pad = p.cg_pad;                          // power of two >= cg, <= 256
+    const int cgi = threadIdx.x & (cg_pad - 1);
+    const int ssub = threadIdx.x / cg_pad, spb = 256 / cg_pad;      // strips per block pass
+    if (cgi < p.cg) {
         const int c0 = cgi * CH;
         const int nv = min(CH, p.c - c0);
-        const int x0 = s * STRIP, x1 = min(p.w_, x0 + STRIP);
         const T* xin = reinterpret_cast<const T*>(p.x);
         const T* din = reinterpret_cast<const T*>(p.dy);
-        float sc[CH], sh[CH], bs[CH];
+        float sc[CH], sh[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int c = min(c0 + j, p.c - 1);
             sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
             sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
-            bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + c] : 1.f;
         }
         float acc[9][CH], db[CH];
 #pragma unroll
@@ -191,42 +197,55 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgParams p) {
             for (int j = 0; j < CH; ++j) acc[t][j] = 0.f;
 #pragma unroll
         for (int j = 0; j < CH; ++j) db[j] = 0.f;
-        // window of output gradients at columns xc-1, xc, xc+1 (zero outside this strip)
-        float d0[CH], d1[CH], d2[CH];
+        const long nstrip_total = (long)p.n * p.h * p.nstrips;
+        for (long sidx = (long)blockIdx.x * spb + ssub; sidx < nstrip_total; sidx += (long)gridDim.x * spb) {
+            const unsigned su = (unsigned)sidx;
+            const unsigned q = su / (unsigned)p.nstrips;
+            const int s = (int)(su - q * (unsigned)p.nstrips);
+            const int b = (int)(q / (unsigned)p.h), y = (int)(q - (unsigned)b * (unsigned)p.h);
+            const int x0 = s * STRIP, x1 = min(p.w_, x0 + STRIP);
+            float bs[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { d0[j] = 0.f; d1[j] = 0.f; d2[j] = 0.f; }
-        const T* drow = din + (((long)b * p.h + y) * p.w_) * p.ldd + c0;
-        for (int xc = x0 - 1; xc <= x1; ++xc) {
-            // shift: now d1 = dy[xc], d0 = dy[xc-1]; load d2 = dy[xc+1]
+            for (int j = 0; j < CH; ++j)
+                bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + min(c0 + j, p.c - 1)] : 1.f;
+            float d0[CH], d1[CH], d2[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { d0[j] = d1[j]; d1[j] = d2[j]; }
-            const int xn = xc + 1;
-            if (xn >= x0 && xn < x1) loadv<T, CH>(drow + (long)xn * p.ldd, d2, nv);
-            else {
+            for (int j = 0; j < CH; ++j) { d0[j] = 0.f; d1[j] = 0.f; d2[j] = 0.f; }
+            const T* drow = din + (((long)b * p.h + y) * p.w_) * p.ldd + c0;
+            for (int xc = x0 - 1; xc <= x1; ++xc) {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) d2[j] = 0.f;
-            }
-            if (xc >= x0 && xc < x1) {
+                for (int j = 0; j < CH; ++j) { d0[j] = d1[j]; d1[j] = d2[j]; }
+                const int xn = xc + 1;
+                if (xn >= x0 && xn < x1) loadv<T, CH>(drow + (long)xn * p.ldd, d2, nv);
+                else {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) db[j] += d1[j];
-            }
-            if (xc < 0 || xc >= p.w_) continue;
-#pragma unroll
-            for (int dyy = 0; dyy < 3; ++dyy) {
-                const int yy = y + dyy - 1;
-                if (yy < 0 || yy >= p.h) continue;
-                float v[CH];
-                loadv<T, CH>(xin + (((long)b * p.h + yy) * p.w_ + xc) * p.ldx + c0, v, nv);
-                if constexpr (HAS_PRO) {
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) v[j] = act_apply(fmaf(v[j], sc[j], sh[j]), p.pro.act) * bs[j];
+                    for (int j = 0; j < CH; ++j) d2[j] = 0.f;
                 }
-                // x(yy,xc) pairs with dy(y, xc+1-tx) for tap (dyy, tx)
+                if (xc >= x0 && xc < x1) {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    acc[dyy * 3 + 2][j] = fmaf(v[j], d0[j], acc[dyy * 3 + 2][j]);
-                    acc[dyy * 3 + 1][j] = fmaf(v[j], d1[j], acc[dyy * 3 + 1][j]);
-                    acc[dyy * 3 + 0][j] = fmaf(v[j], d2[j], acc[dyy * 3 + 0][j]);
+                    for (int j = 0; j < CH; ++j) db[j] += d1[j];
+                }
+                if (xc < 0 || xc >= p.w_) continue;
+#pragma unroll
+                for (int dyy = 0; dyy < 3; ++dyy) {
+                    const int yy = y + dyy - 1;
+                    if (yy < 0 || yy >= p.h) continue;
+                    float v[CH];
+                    loadv<T, CH>(xin + (((long)b * p.h + yy) * p.w_ + xc) * p.ldx + c0, v, nv);
+                    if constexpr (HAS_PRO) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) v[j] = act_t<ACT>(fmaf(v[j], sc[j], sh[j]), p.pro.act);
+                        if (p.pro.bscale) {
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) v[j] *= bs[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        acc[dyy * 3 + 2][j] = fmaf(v[j], d0[j], acc[dyy * 3 + 2][j]);
+                        acc[dyy * 3 + 1][j] = fmaf(v[j], d1[j], acc[dyy * 3 + 1][j]);
+                        acc[dyy * 3 + 0][j] = fmaf(v[j], d2[j], acc[dyy * 3 + 0][j]);
+                    }
                 }
             }
         }
@@ -255,8 +274,9 @@ int launch_fwd(DwParams& p, bool has_pro, hipStream_t s) {
     p.items = (long)p.n * p.h * p.nstrips * p.cg;
     const int grid = cdiv(p.items, 256);
     const size_t lds = p.stats ? 2 * (size_t)p.c * 4 : 0;
-    if (has_pro) hipLaunchKernelGGL((dw_fwd_kernel<T, CH, true>), dim3(grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((dw_fwd_kernel<T, CH, false>), dim3(grid), dim3(256), lds, s, p);
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw_fwd_kernel<T, CH, true, ISA_ACT_RELU6>), dim3(grid), dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((dw_fwd_kernel<T, CH, true, ACT_RT>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dw_fwd_kernel<T, CH, false, ISA_ACT_NONE>), dim3(grid), dim3(256), lds, s, p);
     return launch_status();
 }
 
@@ -276,12 +296,18 @@ int dw_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const flo
 template <typename T, int CH>
 int launch_wg(DwWgParams& p, bool has_pro, hipStream_t s) {
     p.cg = (p.c + CH - 1) / CH;
+    p.cg_pad = 1;
+    while (p.cg_pad < p.cg) p.cg_pad <<= 1;
+    if (p.cg_pad > 256) return ISA_EINVAL;
     p.nstrips = (p.w_ + STRIP - 1) / STRIP;
     p.items = (long)p.n * p.h * p.nstrips * p.cg;
-    const int grid = cdiv(p.items, 256);
+    const long strips = (long)p.n * p.h * p.nstrips;
+    if (strips >= (1L << 32)) return ISA_EINVAL;
+    const int grid = grid_cap(cdiv(strips, 256 / p.cg_pad), 512);
     const size_t lds = 10 * (size_t)p.c * 4;
-    if (has_pro) hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, true>), dim3(grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, false>), dim3(grid), dim3(256), lds, s, p);
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, true, ISA_ACT_RELU6>), dim3(grid), dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, true, ACT_RT>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, false, ISA_ACT_NONE>), dim3(grid), dim3(256), lds, s, p);
     return launch_status();
 }
 

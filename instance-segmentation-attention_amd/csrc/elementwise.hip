@@ -65,8 +65,11 @@ __global__ void bn_finalize_kernel(const float* stats, float count, const float*
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
         float mean, var;
         if (stats) {
-            mean = stats[i] / count;
-            var = fmaxf(stats[c + i] / count - mean * mean, 0.f);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < ISA_STAT_R; ++r) { s1 += stats[r * 2 * c + i]; s2 += stats[r * 2 * c + c + i]; }
+            mean = s1 / count;
+            var = fmaxf(s2 / count - mean * mean, 0.f);
             if (rm) rm[i] = (1.f - momentum) * rm[i] + momentum * mean;
             if (rv) rv[i] = (1.f - momentum) * rv[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
         } else {
@@ -108,8 +111,19 @@ static inline Walk mkwalk(int c, long pixels) {
 }
 static inline int walk_grid(const Walk& w) { return grid_cap(cdiv(w.pixels, 256 >> w.sh)); }
 
+// red[0][i] = sum_r red[r][i]: collapse the statistic replicas once, so the streaming pass reads 2 floats
+// per channel instead of 2*ISA_STAT_R
+__global__ void collapse_replicas_kernel(float* red, int n2c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2c; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < ISA_STAT_R; ++r) s += red[r * n2c + i];
+        red[i] = s;
+    }
+}
+
 // z = scale*y+shift ; dz = dt * bscale * act'(z)
-template <typename T, bool APPLY>
+template <typename T, bool APPLY, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
     extern __shared__ float red[];              // reduce pass: [2*C]
     const int C = p.y.c;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
     } else if (blockIdx.x == 0 && p.train) {
-        for (int i = threadIdx.x; i < C; i += 256) {
+        for (int i = threadIdx.x; i < C; i += 256) {        // p.red: replicas already collapsed into [0]
             if (p.dgamma) atomicAdd(p.dgamma + i, p.red[C + i]);
             if (p.dbeta) atomicAdd(p.dbeta + i, p.red[i]);
         }
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float z = fmaf(yv[j], sc[j], sh[j]);
-                float dz = dt[j] * act_grad(z, p.act);
+                float dz = dt[j] * act_grad_t<ACT>(z, p.act);
                 if (bs) dz *= bs[min(c0 + j, C - 1)];
                 const float yh = (yv[j] - mu[j]) * is[j];
                 if (!APPLY) { s0[j] += dz; s1[j] += dz * yh; }
@@ -165,14 +179,15 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
     }
     if (!APPLY) {
         __syncthreads();
+        float* rep = p.out_red + (blockIdx.x & (ISA_STAT_R - 1)) * 2 * C;
         for (int i = threadIdx.x; i < 2 * C; i += 256)
-            if (red[i] != 0.f) atomicAdd(p.out_red + i, red[i]);
+            if (red[i] != 0.f) atomicAdd(rep + i, red[i]);
     }
 }
 
 // out = (pro(x) (+ res) (+ res2)) * oscale[b,c]
 struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; };
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) {
     const int C = p.x.c;
     const int ppb = 256 >> wk.sh;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) 
             const long bofs = per_image ? (long)((unsigned)pix / hw) * C : 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float z = act_apply(fmaf(v[j], sc[j], sh[j]), p.pro.act);
+                float z = act_t<ACT>(fmaf(v[j], sc[j], sh[j]), p.pro.act);
                 if (p.pro.bscale) z *= p.pro.bscale[bofs + min(c0 + j, C - 1)];
                 v[j] = z;
             }
@@ -477,16 +492,23 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
     if (p.pixels >= (1L << 32)) return ISA_EINVAL;
     const Walk wk = mkwalk(y->c, p.pixels);
-    const int grid = walk_grid(wk);
+    int grid = walk_grid(wk);
+    if (!apply && grid > 1024) grid = 1024;     // every block ends with 2C global atomics (8 replicas)
     const size_t lds = apply ? 0 : 2 * (size_t)y->c * 4;
-    if (apply)
-        DISPATCH_T(y->dtype,
-            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk),
-            hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk));
-    else
-        DISPATCH_T(y->dtype,
-            hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk),
-            hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk));
+#define BN_BWD_LAUNCH(AP, ACTV) \
+    DISPATCH_T(y->dtype, \
+        hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk), \
+        hipLaunchKernelGGL((bn_bwd_kernel<float, AP, ACTV>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk))
+    if (apply) {
+        if (p.act == ISA_ACT_RELU6) BN_BWD_LAUNCH(true, ISA_ACT_RELU6);
+        else if (p.act == ISA_ACT_NONE) BN_BWD_LAUNCH(true, ISA_ACT_NONE);
+        else BN_BWD_LAUNCH(true, ACT_RT);
+    } else {
+        if (p.act == ISA_ACT_RELU6) BN_BWD_LAUNCH(false, ISA_ACT_RELU6);
+        else if (p.act == ISA_ACT_NONE) BN_BWD_LAUNCH(false, ISA_ACT_NONE);
+        else BN_BWD_LAUNCH(false, ACT_RT);
+    }
+#undef BN_BWD_LAUNCH
     return launch_status();
 }
 
@@ -506,6 +528,9 @@ extern "C" int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const
                                 const float* red, float count, int32_t train,
                                 const isa_tensor* dy, float* dgamma, float* dbeta, void* stream) {
     if (train && !red) return ISA_EINVAL;
+    if (train)      // red is [ISA_STAT_R][2C]; fold it into replica 0 (the caller's buffer is scratch)
+        hipLaunchKernelGGL(collapse_replicas_kernel, dim3(cdiv(2 * y->c, 256)), dim3(256), 0, as_stream(stream),
+                           const_cast<float*>(red), 2 * y->c);
     BnBwdParams p{};
     p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.bscale = bscale;
     p.gamma = gamma; p.red = red; p.inv_count = count > 0 ? 1.f / count : 0.f;
@@ -528,9 +553,14 @@ extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const
     if (p.pixels >= (1L << 32)) return ISA_EINVAL;
     const Walk wk = mkwalk(x->c, p.pixels);
     const int grid = walk_grid(wk);
-    DISPATCH_T(x->dtype,
-        hipLaunchKernelGGL(materialize_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
-        hipLaunchKernelGGL(materialize_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
+    if (p.pro.act == ISA_ACT_NONE)
+        DISPATCH_T(x->dtype,
+            hipLaunchKernelGGL((materialize_kernel<bf16_t, ISA_ACT_NONE>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((materialize_kernel<float, ISA_ACT_NONE>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
+    else
+        DISPATCH_T(x->dtype,
+            hipLaunchKernelGGL((materialize_kernel<bf16_t, ACT_RT>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((materialize_kernel<float, ACT_RT>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
     return launch_status();
 }
 

@@ -17,6 +17,9 @@ import torch
 from . import lib as L
 
 
+STAT_R = 8      # ISA_STAT_REPLICAS: statistics buffers are [8][2C]
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 
@@ -444,7 +447,7 @@ class Engine:
         reg = self.reg_conv(wname, taps, kmap, transposed)
         in_mode = L.IN_3X3 if taps == 9 else L.IN_1X1
         out_mode = L.OUT_SHUFFLE2 if transposed else L.OUT_PLAIN
-        st = self.scratch(2 * out.c) if stats else None
+        st = self.scratch(2 * out.c * STAT_R) if stats else None
         job = (x, reg, bias, out, in_mode, out_mode, st)
         self._launch_conv(*job)
         self._last_conv = dict(reg=reg, in_mode=in_mode)
@@ -500,7 +503,7 @@ class Engine:
         reg = self.reg_dw(wname, kmap)
         if self.packer.table is None:
             self.packer.pack()
-        st = self.scratch(2 * out.c) if stats else None
+        st = self.scratch(2 * out.c * STAT_R) if stats else None
         if self.profile:
             self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
         L.check(self.lib.isa_dwconv3x3(x.d(), x.p(), self.packer.ptr(reg["fwd"]),
@@ -549,7 +552,7 @@ class Engine:
     def _bn_backward(self, lazy: Act, dt: Act, dy: Act, bscale):
         b = lazy.bn
         P = self.params
-        red = self.scratch(2 * lazy.c) if b["train"] else None
+        red = self.scratch(2 * lazy.c * STAT_R) if b["train"] else None
         if b["train"]:
             L.check(self.lib.isa_bn_bwd_reduce(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
                                                L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),

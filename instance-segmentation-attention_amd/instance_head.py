@@ -75,7 +75,7 @@ class InstanceHead:
                                      P.ptr(pre + ".spatial_fc.1.weight"), P.ptr(pre + ".spatial_fc.1.bias"),
                                      n, c, Lp, L.ptr(beta), L.ptr(rowstat), E.st()), "isa_sp_softmax")
         scale, shift, mean, invstd = (E.f32(c) for _ in range(4))
-        stats = E.scratch(2 * c)
+        stats = E.scratch(2 * c * 8)
         if E.bn_train:
             L.check(E.lib.isa_scaled_stats(x.d(), L.ptr(beta), L.ptr(stats), E.st()), "isa_scaled_stats")
             P.int_buffers[pre + ".bn.num_batches_tracked"] += 1

@@ -37,9 +37,9 @@ def main(dtype=torch.bfloat16, which=None):
         sc, sh = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda")
         xl = x.with_pro(Pro(sc, sh, L.ACT_RELU6))
         nbytes = B * hw * hw * c * esz
-        st = torch.zeros(2 * c, device="cuda")
+        st = torch.zeros(16 * c, device="cuda")
         mean, inv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
-        red = torch.zeros(2 * c, device="cuda")
+        red = torch.zeros(16 * c, device="cuda")
         reg = eng.reg_conv("w"); regd = eng.reg_dw("wd"); eng.packer.pack()
         lib = eng.lib
         tests = {

@@ -85,7 +85,7 @@ def test_conv1x1(dtype, cin, cout, hw, batch):
     # untouched padding channels
     assert float((ya.buf[..., cout:].float() - 5.0).abs().max()) == 0.0
     # fused BN statistics
-    s = st.cpu()
+    s = st.cpu().view(8, -1).sum(0)
     assert rel(s[:cout], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
     assert rel(s[cout:2 * cout], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
 
@@ -162,7 +162,7 @@ def test_dwconv(dtype, c, h, w):
     xt = torch.clamp(q(x, dtype) * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
     ref = F.conv2d(xt, q(wt, dtype), b, padding=1, groups=c)
     assert rel(ya.nchw(), ref) < TOL[dtype]
-    s = st.cpu()
+    s = st.cpu().view(8, -1).sum(0)
     assert rel(s[:c], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
     assert rel(s[c:2 * c], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
 
@@ -183,7 +183,9 @@ def test_bn_finalize_and_materialize(dtype):
         eng.bn_train = train
         xa = to_act(Act, x, dtype)
         xq = q(x, dtype)
-        st = torch.cat([xq.sum((0, 2, 3)), (xq * xq).sum((0, 2, 3))]).cuda()
+        st = torch.zeros(8, 2 * c)
+        st[0] = torch.cat([xq.sum((0, 2, 3)), (xq * xq).sum((0, 2, 3))])
+        st = st.reshape(-1).cuda()
         out = eng.new_act(batch, hw, hw, c)
         eng.bn_out(xa, st, "bn", L.ACT_RELU6, out, res=to_act(Act, res, dtype))
         torch.cuda.synchronize()
