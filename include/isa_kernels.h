@@ -92,13 +92,15 @@ int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_
                   const float* bias, const isa_tensor* y, int32_t in_mode, int32_t out_mode,
                   float* stats, int32_t accumulate, void* stream);
 
-/* Weight gradient of the same family, accumulated (fp32 atomics) straight into the reference's
- * state_dict layout: dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)
+/* Weight gradient of the same family, accumulated straight into the reference's state_dict layout:
+ * dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)
  *   += sum_m dy[m,n] * pro(x)[m@tap, kd],  kd -> k through kmap (NULL = identity, -1 = padding).
- * dbias[N] += sum_m dy (optional, not for SHUFFLE2: use isa_colsum).                           */
+ * dbias[N] += sum_m dy (optional, not for SHUFFLE2: use isa_colsum).
+ * Two launches, no atomics (deterministic): split-M workgroups write partial slabs into `ws`
+ * (caller scratch, >= a few MB; the split factor adapts to ws_floats), a reduce kernel folds them. */
 int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                    float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
-                   const int32_t* kmap, int32_t ksrc, void* stream);
+                   const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats, void* stream);
 /* out[c] += sum over all pixels of x[.,c]  (bias gradients) */
 int isa_colsum(const isa_tensor* x, float* out, void* stream);
 

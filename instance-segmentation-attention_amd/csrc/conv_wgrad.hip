@@ -32,6 +32,8 @@ struct WgParams {
     int N, taps, in_mode, out_mode;
     int groups_k;
     long nchunks;
+    long ws_floats;            // host side: capacity of ws
+    float* ws;                 // [gridDim.x][gridDim.y][taps][TN*TK*1024 (+ TN*32 bias sums)] partial slabs
 };
 
 template <typename T>
@@ -71,37 +73,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     for (int i = 0; i < TN; ++i) dbs[i] = 0.f;
 
     float rd[LOADS_N][8], rx[LOADS_K][8];
+    const int cgn = lane % VN, rown = lane / VN, cgk = lane % VK, rowk = lane / VK;
+    constexpr int RPN = 64 / VN, RPK = 64 / VK;
+    const int cn0 = n0 + cgn * 8, ck0 = k0 + cgk * 8;
+    const bool has_pro = p.pro.scale || p.pro.shift || p.pro.bscale || p.pro.act != ISA_ACT_NONE;
+    float psc[8], psh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = min(ck0 + j, p.cin - 1);
+        psc[j] = p.pro.scale ? p.pro.scale[c] : 1.f;
+        psh[j] = p.pro.shift ? p.pro.shift[c] : 0.f;
+    }
 
     // global -> registers for one chunk (prologue applied to x here)
     auto fetch = [&](long chunk) {
         const long mbase = chunk * PM;
 #pragma unroll
         for (int v = 0; v < LOADS_N; ++v) {
-            const int idx = v * 64 + lane, pix = idx / VN, c0 = n0 + (idx % VN) * 8;
-            const long m = mbase + pix;
+            const long m = mbase + v * RPN + rown;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rd[v][j] = 0.f;
-            if (m < p.M && c0 < p.N) {
+            if (m < p.M && cn0 < p.N) {
                 long row = m;
                 if (p.out_mode == ISA_OUT_SHUFFLE2) {
-                    const int px = (int)(m % p.mw); const long q = m / p.mw;
-                    const int py = (int)(q % p.mh); const long pb = q / p.mh;
-                    row = (pb * p.dh + 2 * py + (tap >> 1)) * p.dw_ + 2 * px + (tap & 1);
+                    const unsigned mu = (unsigned)m, q = mu / (unsigned)p.mw;
+                    const int px = (int)(mu - q * (unsigned)p.mw);
+                    const unsigned pb = q / (unsigned)p.mh; const int py = (int)(q - pb * (unsigned)p.mh);
+                    row = ((long)pb * p.dh + 2 * py + (tap >> 1)) * p.dw_ + 2 * px + (tap & 1);
                 }
-                ldvec<T>(din + row * p.ldd + c0, rd[v], p.N - c0);
+                ldvec<T>(din + row * p.ldd + cn0, rd[v], p.N - cn0);
             }
         }
 #pragma unroll
         for (int v = 0; v < LOADS_K; ++v) {
-            const int idx = v * 64 + lane, pix = idx / VK, c0 = k0 + (idx % VK) * 8;
-            const long m = mbase + pix;
+            const long m = mbase + v * RPK + rowk;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rx[v][j] = 0.f;
-            if (m < p.M && c0 < p.cin) {
+            if (m < p.M && ck0 < p.cin) {
                 long row = m; bool ok = true; long pb = 0;
                 if (!plain || p.pro.bscale) {
-                    const int px = (int)(m % p.mw); const long q = m / p.mw;
-                    const int py = (int)(q % p.mh); pb = q / p.mh;
+                    const unsigned mu = (unsigned)m, q = mu / (unsigned)p.mw;
+                    const int px = (int)(mu - q * (unsigned)p.mw);
+                    pb = q / (unsigned)p.mh; const int py = (int)(q - (unsigned)pb * (unsigned)p.mh);
                     if (p.in_mode == ISA_IN_3X3) {
                         const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
                         ok = sy >= 0 && sy < p.xh && sx >= 0 && sx < p.xw;
@@ -109,16 +122,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
                     }
                 }
                 if (ok) {
-                    ldvec<T>(xin + row * p.ldx + c0, rx[v], p.cin - c0);
+                    ldvec<T>(xin + row * p.ldx + ck0, rx[v], p.cin - ck0);
+                    if (has_pro) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int c = min(c0 + j, p.cin - 1);
-                        float z = rx[v][j];
-                        if (p.pro.scale) z *= p.pro.scale[c];
-                        if (p.pro.shift) z += p.pro.shift[c];
-                        z = act_t<ACT>(z, p.pro.act);
-                        if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + c];
-                        rx[v][j] = (c0 + j < p.cin) ? z : 0.f;
+                        for (int j = 0; j < 8; ++j) {
+                            float z = act_t<ACT>(fmaf(rx[v][j], psc[j], psh[j]), p.pro.act);
+                            if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + min(ck0 + j, p.cin - 1)];
+                            rx[v][j] = (ck0 + j < p.cin) ? z : 0.f;
+                        }
                     }
                 }
             }
@@ -127,21 +138,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     auto stash = [&]() {          // registers -> wave-private LDS slab
 #pragma unroll
         for (int v = 0; v < LOADS_N; ++v) {
-            const int idx = v * 64 + lane, pix = idx / VN, col = (idx % VN) * 8;
             f32x4 a, b;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a[j] = rd[v][j]; b[j] = rd[v][4 + j]; }
-            *reinterpret_cast<f32x4*>(sD + pix * LDN + col) = a;
-            *reinterpret_cast<f32x4*>(sD + pix * LDN + col + 4) = b;
+            float* d = sD + (v * RPN + rown) * LDN + cgn * 8;
+            *reinterpret_cast<f32x4*>(d) = a;
+            *reinterpret_cast<f32x4*>(d + 4) = b;
         }
 #pragma unroll
         for (int v = 0; v < LOADS_K; ++v) {
-            const int idx = v * 64 + lane, pix = idx / VK, col = (idx % VK) * 8;
             f32x4 a, b;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a[j] = rx[v][j]; b[j] = rx[v][4 + j]; }
-            *reinterpret_cast<f32x4*>(sX + pix * LDK + col) = a;
-            *reinterpret_cast<f32x4*>(sX + pix * LDK + col + 4) = b;
+            float* d = sX + (v * RPK + rowk) * LDK + cgk * 8;
+            *reinterpret_cast<f32x4*>(d) = a;
+            *reinterpret_cast<f32x4*>(d + 4) = b;
         }
     };
 
@@ -195,33 +206,289 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
         __syncthreads();
     }
     if (wave != 0) return;
+    // one partial slab per workgroup, raw fragment layout (256-byte coalesced stores); wgrad_reduce_kernel
+    // sums the gridDim.x slabs of each (group, tap) in a fixed order and adds into dW: no atomics, so no
+    // same-line serialisation at the memory side, and bitwise-reproducible weight gradients.
+    constexpr int SLABF = TN * TK * 1024 + TN * 32;
+    float* slab = p.ws + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * SLABF;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j) {
+    for (int e = 0; e < TN * TK * 16; ++e) slab[e * 64 + lane] = red[e * 64 + lane];
+    for (int i = lane; i < TN * 32; i += 64) slab[TN * TK * 1024 + i] = red[ACC_FLOATS + i];
+}
+
+// second stage of the weight gradient: dW (+ dbias) += sum over the gx partial slabs
+constexpr int RSPLIT = 16;
+struct WgReduce {
+    const float* ws; float* dw; float* dbias; const int32_t* kmap;
+    int gx, gy, taps, groups_k, tn, tk, N, cin, ksrc, out_mode;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
+    // grid = (slab elements / 256, tile groups, taps * RSPLIT): each thread folds 1/RSPLIT of the gx slabs
+    // of one fragment element (coalesced 256-byte reads, independent loads) and adds it with ONE atomic:
+    // RSPLIT adders per address instead of gx.
+    const int slabf = q.tn * q.tk * 1024 + q.tn * 32;
+    const int group = blockIdx.y, tap = blockIdx.z / RSPLIT, split = blockIdx.z % RSPLIT;
+    const int gn = group / q.groups_k, gk = group % q.groups_k;
+    const int n0 = gn * q.tn * 32, k0 = gk * q.tk * 32;
+    const int per = (q.gx + RSPLIT - 1) / RSPLIT;
+    const int b0 = split * per, b1 = min(q.gx, b0 + per);
+    if (b0 >= b1) return;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < slabf; idx += gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int bx = b0; bx < b1; ++bx)
+            s += q.ws[(((long)bx * q.gy + group) * q.taps + tap) * slabf + idx];
+        if (idx < q.tn * q.tk * 1024) {
+            const int lane = idx & 63, e = (idx >> 6) & 15, t = idx >> 10;
+            const int i = t / q.tk, j = t - i * q.tk;
+            const int r = lane & 31, hh = lane >> 5;
             const int kd = k0 + j * 32 + r;
-            if (kd >= p.cin) continue;
-            const int k = p.kmap ? p.kmap[kd] : kd;
+            const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (kd >= q.cin || n >= q.N) continue;
+            const int k = q.kmap ? q.kmap[kd] : kd;
             if (k < 0) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (n >= p.N) continue;
-                const float v = red[((i * TK + j) * 16 + e) * 64 + lane];
-                long off;
-                if (p.out_mode == ISA_OUT_SHUFFLE2) off = ((long)k * p.N + n) * 4 + tap;   // [K][Co][2][2]
-                else off = ((long)n * p.ksrc + k) * p.taps + tap;                          // [N][K][kh][kw]
-                atomicAdd(p.dw + off, v);
-            }
-        }
-    if (p.dbias && gk == 0 && tap == 0 && hh == 0) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + i * 32 + r;
-            if (n < p.N) atomicAdd(p.dbias + n, red[ACC_FLOATS + i * 32 + r]);
+            long off;
+            if (q.out_mode == ISA_OUT_SHUFFLE2) off = ((long)k * q.N + n) * 4 + tap;       // [K][Co][2][2]
+            else off = ((long)n * q.ksrc + k) * q.taps + tap;                              // [N][K][kh][kw]
+            atomicAdd(q.dw + off, s);
+        } else if (q.dbias && gk == 0 && tap == 0) {
+            const int n = n0 + (idx - q.tn * q.tk * 1024);
+            if (n < q.N) atomicAdd(q.dbias + n, s);
         }
     }
 }
+
+static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipStream_t s) {
+    WgReduce q{p.ws, p.dw, p.dbias, p.kmap, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode};
+    const int slabf = tn * tk * 1024 + tn * 32;
+    dim3 grid(cdiv(slabf, 256), gy, p.taps * RSPLIT);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, s, q);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage: the same contraction on v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate, which
+// otherwise bounds this kernel: 2*M*N*K flops at 157 TF/s ~ the HBM time of the two operands).
+// Operands A[i=n][k=pixel 8h+j] / B[k=pixel 8h+j][j=k-channel] need 8 consecutive PIXELS of one
+// channel per lane: the tiles are staged row-major [pixel][channel] in LDS (coalesced 16-byte loads,
+// prologue applied in fp32 then rounded once, exactly like conv_gemm's forward operand) and fetched
+// with ds_read_b64_tr_b16, the hardware transpose read (lane (r,h) element j <- tile[8h+j][r];
+// verified by scripts/probes/tr_probe.hip).  Row stride is kept == 64 (mod 256) bytes so the four
+// 64-byte row pieces a half-wave touches land on disjoint banks.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
+
+template <int CH> struct TrStride { static constexpr int bytes = (CH * 2) % 128 == 0 ? CH * 2 + 64 : CH * 2; };
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride_bytes, int pix0, int chan0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const char* a = tile + (pix0 + 8 * (g >> 1) + q) * stride_bytes + (chan0 + 16 * (g & 1) + 4 * pp) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a + 4 * stride_bytes));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TN, int TK, int ACT>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    constexpr int PMB = 32;                                   // pixels per wave-chunk = 2 MFMA k-steps
+    constexpr int SN = TrStride<TN * 32>::bytes, SK = TrStride<TK * 32>::bytes;
+    constexpr int SLAB = PMB * (SN + SK);
+    constexpr int VN = TN * 4, VK = TK * 4;
+    constexpr int LOADS_N = PMB * VN / 64, LOADS_K = PMB * VK / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int gn = blockIdx.y / p.groups_k, gk = blockIdx.y % p.groups_k;
+    const int tap = blockIdx.z;
+    const int n0 = gn * TN * 32, k0 = gk * TK * 32;
+    char* sD = ldsb + wave * SLAB;
+    char* sX = sD + PMB * SN;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* din = reinterpret_cast<const bf16_t*>(p.dy);
+    const bool plain = p.in_mode == ISA_IN_1X1 && p.out_mode == ISA_OUT_PLAIN;
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = f32x16{0};
+    float dbs[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) dbs[i] = 0.f;
+    bf16x8 rd[LOADS_N], rx[LOADS_K];
+    const long nchunks = (p.M + PMB - 1) / PMB;
+    // a lane keeps ONE 8-channel group of each operand for the whole kernel (VN, VK divide 64), so the
+    // prologue constants are loaded once into registers instead of per element per chunk
+    const int cgn = lane % VN, rown = lane / VN, cgk = lane % VK, rowk = lane / VK;
+    constexpr int RPN = 64 / VN, RPK = 64 / VK;           // pixel rows covered per load instruction
+    const int cn0 = n0 + cgn * 8, ck0 = k0 + cgk * 8;
+    const bool has_aff = p.pro.scale || p.pro.shift;
+    const bool has_pro = has_aff || p.pro.bscale || p.pro.act != ISA_ACT_NONE;
+    float psc[8], psh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = min(ck0 + j, p.cin - 1);
+        psc[j] = p.pro.scale ? p.pro.scale[c] : 1.f;
+        psh[j] = p.pro.shift ? p.pro.shift[c] : 0.f;
+    }
+
+    auto fetch = [&](long chunk) {
+        const long mbase = chunk * PMB;
+#pragma unroll
+        for (int v = 0; v < LOADS_N; ++v) {
+            const long m = mbase + v * RPN + rown;
+            rd[v] = bf16x8{0};
+            if (m < p.M && cn0 < p.N) {
+                long row = m;
+                if (p.out_mode == ISA_OUT_SHUFFLE2) {
+                    const unsigned mu = (unsigned)m, q = mu / (unsigned)p.mw;
+                    const int px = (int)(mu - q * (unsigned)p.mw);
+                    const unsigned pb = q / (unsigned)p.mh; const int py = (int)(q - pb * (unsigned)p.mh);
+                    row = ((long)pb * p.dh + 2 * py + (tap >> 1)) * p.dw_ + 2 * px + (tap & 1);
+                }
+                const bf16_t* src = din + row * p.ldd + cn0;
+                if (cn0 + 8 <= p.N) rd[v] = *reinterpret_cast<const bf16x8*>(src);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rd[v][j] = (cn0 + j < p.N) ? src[j] : (bf16_t)0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < LOADS_K; ++v) {
+            const long m = mbase + v * RPK + rowk;
+            rx[v] = bf16x8{0};
+            if (m < p.M && ck0 < p.cin) {
+                long row = m; bool ok = true; long pb = 0;
+                if (!plain || p.pro.bscale) {
+                    const unsigned mu = (unsigned)m, q = mu / (unsigned)p.mw;
+                    const int px = (int)(mu - q * (unsigned)p.mw);
+                    pb = q / (unsigned)p.mh; const int py = (int)(q - (unsigned)pb * (unsigned)p.mh);
+                    if (p.in_mode == ISA_IN_3X3) {
+                        const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
+                        ok = sy >= 0 && sy < p.xh && sx >= 0 && sx < p.xw;
+                        row = (pb * p.xh + sy) * p.xw + sx;
+                    }
+                }
+                if (ok) {
+                    const bf16_t* src = xin + row * p.ldx + ck0;
+                    bf16x8 raw;
+                    if (ck0 + 8 <= p.cin) raw = *reinterpret_cast<const bf16x8*>(src);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) raw[j] = (ck0 + j < p.cin) ? src[j] : (bf16_t)0.f;
+                    }
+                    if (has_pro) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float z = act_t<ACT>(fmaf((float)raw[j], psc[j], psh[j]), p.pro.act);
+                            if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + min(ck0 + j, p.cin - 1)];
+                            raw[j] = (bf16_t)((ck0 + j < p.cin) ? z : 0.f);
+                        }
+                    }
+                    rx[v] = raw;
+                }
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int v = 0; v < LOADS_N; ++v)
+            *reinterpret_cast<bf16x8*>(sD + (v * RPN + rown) * SN + cgn * 16) = rd[v];
+#pragma unroll
+        for (int v = 0; v < LOADS_K; ++v)
+            *reinterpret_cast<bf16x8*>(sX + (v * RPK + rowk) * SK + cgk * 16) = rx[v];
+    };
+
+    const long stride = (long)gridDim.x * 4;
+    long chunk = (long)blockIdx.x * 4 + wave;
+    if (chunk < nchunks) fetch(chunk);
+    for (; chunk < nchunks; chunk += stride) {
+        stash();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (chunk + stride < nchunks) fetch(chunk + stride);
+#pragma unroll
+        for (int s = 0; s < PMB / 16; ++s) {
+            bf16x8 a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                a[i] = tr_frag(sD, SN, 16 * s, i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dbs[i] += (float)a[i][j];
+            }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = tr_frag(sX, SK, 16 * s, j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    constexpr int ACC_FLOATS = TN * TK * 16 * 64;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* q = red + ((i * TK + j) * 16 + e) * 64 + lane;
+                        *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
+                    }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const float sv = dbs[i] + __shfl_xor(dbs[i], 32, 64);
+                if (hh == 0) { float* q = red + ACC_FLOATS + i * 32 + r; *q = (w == 0 ? 0.f : *q) + sv; }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    // one partial slab per workgroup, raw fragment layout (256-byte coalesced stores); wgrad_reduce_kernel
+    // sums the gridDim.x slabs of each (group, tap) in a fixed order and adds into dW: no atomics, so no
+    // same-line serialisation at the memory side, and bitwise-reproducible weight gradients.
+    constexpr int SLABF = TN * TK * 1024 + TN * 32;
+    float* slab = p.ws + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * SLABF;
+#pragma unroll
+    for (int e = 0; e < TN * TK * 16; ++e) slab[e * 64 + lane] = red[e * 64 + lane];
+    for (int i = lane; i < TN * 32; i += 64) slab[TN * TK * 1024 + i] = red[ACC_FLOATS + i];
+}
+
+template <int TN, int TK>
+int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
+    constexpr int SN = TrStride<TN * 32>::bytes, SK = TrStride<TK * 32>::bytes;
+    const size_t slab = (size_t)32 * (SN + SK) * 4;
+    const size_t redb = ((size_t)TN * TK * 16 * 64 + TN * 32) * 4;
+    const size_t lds = slab > redb ? slab : redb;
+    const int gy = groups_n * p.groups_k;
+    const long nchunks = (p.M + 31) / 32;
+    const long slabf = (long)TN * TK * 1024 + TN * 32;
+    long want = (nchunks + 3) / 4;
+    long cap = (256L * 3) / ((long)gy * p.taps);
+    const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
+    if (ws_cap < 1) return ISA_EINVAL;                    // workspace too small for even one slab set
+    if (cap > ws_cap) cap = ws_cap;
+    if (cap < 1) cap = 1;
+    const int gx = (int)(want < cap ? want : cap);
+    dim3 grid(gx, gy, p.taps);
+    if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
+    else if (p.pro.act == ISA_ACT_NONE) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ACT_RT>), grid, dim3(256), lds, s, p);
+    if (launch_status() != ISA_OK) return ISA_ELAUNCH;
+    return launch_reduce(p, gx, gy, TN, TK, s);
+}
+
 
 template <typename T, int TN, int TK>
 int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
@@ -230,15 +497,20 @@ int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
     const size_t redb = ((size_t)TN * TK * 16 * 64 + TN * 32) * 4;
     const size_t lds = slab > redb ? slab : redb;
     const int gy = groups_n * p.groups_k;
+    const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (p.nchunks + 3) / 4;
     long cap = (256L * 2) / ((long)gy * p.taps);
+    const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
+    if (ws_cap < 1) return ISA_EINVAL;
+    if (cap > ws_cap) cap = ws_cap;
     if (cap < 1) cap = 1;
     const int gx = (int)(want < cap ? want : cap);
     dim3 grid(gx, gy, p.taps);
     if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
     else if (p.pro.act == ISA_ACT_NONE) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ACT_RT>), grid, dim3(256), lds, s, p);
-    return launch_status();
+    if (launch_status() != ISA_OK) return ISA_ELAUNCH;
+    return launch_reduce(p, gx, gy, TN, TK, s);
 }
 
 template <typename T>
@@ -250,6 +522,15 @@ int dispatch_wg(WgParams& p, hipStream_t s) {
     else { tn = 2; tk = 2; }
     const int groups_n = (nt + tn - 1) / tn;
     p.groups_k = (kt + tk - 1) / tk;
+    if constexpr (sizeof(T) == 2) {
+        if (tn == 1 && tk == 1) return launch_wg_bf16<1, 1>(p, groups_n, s);
+        if (tn == 1 && tk == 2) return launch_wg_bf16<1, 2>(p, groups_n, s);
+        if (tn == 2 && tk == 1) return launch_wg_bf16<2, 1>(p, groups_n, s);
+        if (tn == 2 && tk == 2) return launch_wg_bf16<2, 2>(p, groups_n, s);
+        if (tn == 1 && tk == 4) return launch_wg_bf16<1, 4>(p, groups_n, s);
+        if (tn == 4 && tk == 1) return launch_wg_bf16<4, 1>(p, groups_n, s);
+        return ISA_EINVAL;
+    }
     if (tn == 1 && tk == 1) return launch_wg<T, 1, 1>(p, groups_n, s);
     if (tn == 1 && tk == 2) return launch_wg<T, 1, 2>(p, groups_n, s);
     if (tn == 2 && tk == 1) return launch_wg<T, 2, 1>(p, groups_n, s);
@@ -263,15 +544,16 @@ int dispatch_wg(WgParams& p, hipStream_t s) {
 
 extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                               float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
-                              const int32_t* kmap, int32_t ksrc, void* stream) {
-    if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
+                              const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats,
+                              void* stream) {
+    if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype || !ws) return ISA_EINVAL;
     if (in_mode == ISA_IN_GATHER2) return ISA_EINVAL;
     WgParams p{};
     p.x = x->data; p.xh = x->h; p.xw = x->w; p.cin = x->c; p.ldx = x->ld;
     p.dy = dy->data; p.dh = dy->h; p.dw_ = dy->w; p.ldd = dy->ld;
     p.mh = x->h; p.mw = x->w; p.M = (long)x->n * x->h * x->w;
     p.pro = make_pro(pro); p.dw = dw; p.dbias = dbias; p.kmap = kmap; p.ksrc = ksrc > 0 ? ksrc : x->c;
-    p.in_mode = in_mode; p.out_mode = out_mode;
+    p.in_mode = in_mode; p.out_mode = out_mode; p.ws = ws; p.ws_floats = ws_floats;
     if (out_mode == ISA_OUT_SHUFFLE2) {
         if (in_mode != ISA_IN_1X1 || dy->h != 2 * x->h || dy->w != 2 * x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = 4; p.N = dy->c;

@@ -371,6 +371,7 @@ class Engine:
         self.stats_size = 0
         self._zero = None
         self.lib = _ProfiledLib(L.lib(), self)
+        self.ws = torch.empty(16 << 20, dtype=torch.float32, device=device)   # 64 MB reduction workspace
         self.profile = False           # when True every launch is bracketed by HIP events
         self.prof_events = []          # (entry point, start event, end event, algorithmic bytes)
         self.next_bytes = 0
@@ -458,7 +459,8 @@ class Engine:
                 if transposed:
                     L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname), None,
                                                     L.IN_1X1, L.OUT_SHUFFLE2, pk.kmap_ptr(reg["fwd"]),
-                                                    self.params.shapes[wname][0], self.st()), "isa_conv_wgrad")
+                                                    self.params.shapes[wname][0], L.ptr(self.ws), self.ws.numel(),
+                                                    self.st()), "isa_conv_wgrad")
                     if bias is not None:
                         L.check(self.lib.isa_colsum(dy.d(), self.params.gptr(bias), self.st()), "isa_colsum")
                 else:
@@ -467,7 +469,8 @@ class Engine:
                     L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                     self.params.gptr(bias) if bias else None, in_mode,
                                                     L.OUT_PLAIN, pk.kmap_ptr(reg["fwd"]),
-                                                    self.params.shapes[wname][1], self.st()), "isa_conv_wgrad")
+                                                    self.params.shapes[wname][1], L.ptr(self.ws), self.ws.numel(),
+                                                    self.st()), "isa_conv_wgrad")
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
                     dx = self.grads.grad_of(x)

@@ -42,7 +42,7 @@ I64 = C.c_int64
 SIGNATURES = {
     "isa_pack_weights": [VP, I32, VP, VP, VP, I32, VP],
     "isa_conv_gemm": [P_T, P_PRO, VP, I32, VP, P_T, I32, I32, VP, I32, VP],
-    "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP],
+    "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP, I64, VP],
     "isa_colsum": [P_T, VP, VP],
     "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],
     "isa_dwconv3x3_dgrad": [P_T, VP, P_T, I32, VP],

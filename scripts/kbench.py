@@ -45,7 +45,8 @@ def main(dtype=torch.bfloat16, which=None):
         tests = {
             "conv1x1": (lambda: lib.isa_conv_gemm(x.d(), None, eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
             "conv1x1+pro": (lambda: lib.isa_conv_gemm(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
-            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.stream_ptr()), 2),
+            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), 2),
+            "wgrad1x1_nopro": (lambda: lib.isa_conv_wgrad(x.d(), None, dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), 2),
             "dw+pro": (lambda: lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(regd["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), 2),
             "dw_dgrad": (lambda: lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(regd["dgrad"]), y.d(), 0, L.stream_ptr()), 2),
             "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.stream_ptr()), 2),

@@ -245,3 +245,68 @@ def test_se_gate_and_argmax():
     L.check(eng.lib.isa_chan_argmax(la.d(), out.d(), eng.st()), "argmax")
     torch.cuda.synchronize()
     assert torch.equal(out.nchw().cpu()[:, 0], lg.argmax(1).float())
+
+
+# ------------------------------------------------------------------------------------------------
+# backward of the convolution family vs torch autograd (weight, bias and data gradients)
+# ------------------------------------------------------------------------------------------------
+BWD_TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
+
+
+def _run_backward(eng, out_act, dy, Act):
+    g = eng.grads.grad_of(out_act)
+    g.buf[..., g.c0:g.c0 + g.c] = dy.permute(0, 2, 3, 1).to(g.buf.dtype).cuda()
+    eng.grads.written[out_act.buf.data_ptr()].append((out_act.c0, out_act.c0 + out_act.c))
+    eng.backward()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,hw", [("1x1", 32, 32, 16), ("1x1", 64, 246, 8), ("1x1", 48, 24, 12),
+                                              ("1x1", 256, 128, 8), ("3x3", 32, 16, 12), ("3x3", 16, 2, 16),
+                                              ("T", 64, 32, 8), ("dw", 32, 32, 16), ("dw", 21, 21, 10)])
+def test_conv_backward(dtype, kind, cin, cout, hw):
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    batch = 2
+    taps = 9 if kind == "3x3" else 1
+    if kind == "T":
+        w = rand(cin, cout, 2, 2, seed=1, scale=cin ** -0.5)
+    elif kind == "dw":
+        w = rand(cin, 1, 3, 3, seed=1, scale=1 / 3.0)
+    else:
+        k = 3 if kind == "3x3" else 1
+        w = rand(cout, cin, k, k, seed=1, scale=(cin * k * k) ** -0.5)
+    b = rand(cout, seed=2)
+    x = rand(batch, cin, hw, hw + 2, seed=3)
+    sc, sh = rand(cin, seed=4).abs() + 0.5, rand(cin, seed=5) + 1.0
+    eng = make_engine(Engine, ParamStore, [("w", w.shape), ("b", b.shape)], dict(w=w, b=b), dtype)
+    eng.begin(bn_train=True, record=True)
+    # lazy input: act(scale*x+shift) with ReLU6, as after a BN; data gradient is w.r.t. that value
+    xa = to_act(Act, x, dtype).with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6))
+    oh, ow = (2 * hw, 2 * (hw + 2)) if kind == "T" else (hw, hw + 2)
+    ya = eng.new_act(batch, oh, ow, cout)
+    if kind == "dw":
+        eng.dwconv(xa, "w", ya, bias="b")
+    else:
+        eng.conv(xa, "w", ya, taps=taps, bias="b", transposed=(kind == "T"))
+    dy = rand(batch, cout, oh, ow, seed=7)
+    _run_backward(eng, ya, dy, Act)
+    # reference
+    xt = torch.clamp(q(x, dtype) * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
+    if dtype == torch.bfloat16 and kind != "dw":
+        xt = q(xt, dtype)                       # the MFMA operand is rounded once to bf16
+    xt.requires_grad_(True)
+    wq = q(w, dtype).requires_grad_(True)
+    bq = b.clone().requires_grad_(True)
+    if kind == "T":
+        yr = F.conv_transpose2d(xt, wq, bq, stride=2)
+    elif kind == "dw":
+        yr = F.conv2d(xt, wq, bq, padding=1, groups=cin)
+    else:
+        yr = F.conv2d(xt, wq, bq, padding=taps // 9)
+    yr.backward(q(dy, dtype))
+    tol = BWD_TOL[dtype]
+    assert rel(eng.params.gview("w"), wq.grad) < tol, "dW"
+    assert rel(eng.params.gview("b"), bq.grad) < tol, "db"
+    dx = eng.grads.grad_of(xa)
+    assert rel(dx.nchw(), xt.grad) < tol, "dX"
