@@ -114,7 +114,7 @@ int isa_dwconv3x3(const isa_tensor* x, const isa_pro* pro, const void* w, const 
 int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const isa_tensor* dx,
                         int32_t accumulate, void* stream);
 int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
-                        float* dw, float* dbias, int32_t csrc, void* stream);
+                        float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, void* stream);
 
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the

@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int STRIP = 16;
+constexpr int WSTRIP = 64;       // weight-gradient strips are longer: the per-strip reduction tail is amortised 4x
 
 struct DwParams {
     const void* x; const void* w; const float* bias; void* y;
@@ -163,6 +164,7 @@ struct DwWgParams {
     int n, h, w_, c, ldx, ldd;
     ProDev pro;
     long items; int nstrips, cg; int csrc; int cg_pad;
+    float* ws;                 // [gridDim.x][10*C] per-workgroup partial sums
 };
 
 // dw[c][t] (reference [C,1,3,3] layout) += sum_p dy[p,c] * xt[p + off(t), c];  dbias[c] += sum_p dy[p,c]
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgParams p) {
             const unsigned q = su / (unsigned)p.nstrips;
             const int s = (int)(su - q * (unsigned)p.nstrips);
             const int b = (int)(q / (unsigned)p.h), y = (int)(q - (unsigned)b * (unsigned)p.h);
-            const int x0 = s * STRIP, x1 = min(p.w_, x0 + STRIP);
+            const int x0 = s * WSTRIP, x1 = min(p.w_, x0 + WSTRIP);
             float bs[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j)
@@ -257,13 +259,26 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgParams p) {
         for (int j = 0; j < CH; ++j) if (j < nv) atomicAdd(&red[9 * p.c + c0 + j], db[j]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * p.c; i += 256) {
-        const int t = i / p.c, c = i - t * p.c;
-        if (c < p.csrc && red[i] != 0.f) atomicAdd(p.dw + c * 9 + t, red[i]);
+    float* slab = p.ws + (long)blockIdx.x * 10 * p.c;       // plain coalesced stores; dw_wgrad_reduce_kernel folds
+    for (int i = threadIdx.x; i < 10 * p.c; i += 256) slab[i] = red[i];
+}
+
+// dw[c][t] += sum over workgroups of slab[t*C + c]; dbias[c] += slab[9*C + c]
+constexpr int DW_RSPLIT = 16;
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* ws, int nblk, int C, int csrc, float* dw, float* dbias) {
+    const int split = blockIdx.y;
+    const int per = (nblk + DW_RSPLIT - 1) / DW_RSPLIT;
+    const int b0 = split * per, b1 = min(nblk, b0 + per);
+    if (b0 >= b1) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 10 * C; i += gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += ws[(long)b * 10 * C + i];
+        const int t = i / C, c = i - t * C;
+        if (c >= csrc) continue;
+        if (t < 9) atomicAdd(dw + c * 9 + t, s);
+        else if (dbias) atomicAdd(dbias + c, s);
     }
-    if (p.dbias)
-        for (int i = threadIdx.x; i < p.c; i += 256)
-            if (i < p.csrc && red[9 * p.c + i] != 0.f) atomicAdd(p.dbias + i, red[9 * p.c + i]);
 }
 
 template <typename T, int CH>
@@ -294,20 +309,24 @@ int dw_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const flo
 }
 
 template <typename T, int CH>
-int launch_wg(DwWgParams& p, bool has_pro, hipStream_t s) {
+int launch_wg(DwWgParams& p, bool has_pro, long ws_floats, hipStream_t s) {
     p.cg = (p.c + CH - 1) / CH;
     p.cg_pad = 1;
     while (p.cg_pad < p.cg) p.cg_pad <<= 1;
     if (p.cg_pad > 256) return ISA_EINVAL;
-    p.nstrips = (p.w_ + STRIP - 1) / STRIP;
+    p.nstrips = (p.w_ + WSTRIP - 1) / WSTRIP;
     p.items = (long)p.n * p.h * p.nstrips * p.cg;
     const long strips = (long)p.n * p.h * p.nstrips;
     if (strips >= (1L << 32)) return ISA_EINVAL;
-    const int grid = grid_cap(cdiv(strips, 256 / p.cg_pad), 512);
+    int grid = grid_cap(cdiv(strips, 256 / p.cg_pad), 1024);
+    const long ws_cap = ws_floats / (10L * p.c);
+    if (ws_cap < 1) return ISA_EINVAL;
+    if (grid > ws_cap) grid = (int)ws_cap;
     const size_t lds = 10 * (size_t)p.c * 4;
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, true, ISA_ACT_RELU6>), dim3(grid), dim3(256), lds, s, p);
     else if (has_pro) hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, true, ACT_RT>), dim3(grid), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((dw_wgrad_kernel<T, CH, false, ISA_ACT_NONE>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(10 * p.c, 256), DW_RSPLIT), dim3(256), 0, s, p.ws, grid, p.c, p.csrc, p.dw, p.dbias);
     return launch_status();
 }
 
@@ -325,7 +344,8 @@ extern "C" int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const is
 }
 
 extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
-                                   float* dw, float* dbias, int32_t csrc, void* stream) {
+                                   float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats,
+                                   void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (x->n != dy->n || x->h != dy->h || x->w != dy->w || x->c != dy->c) return ISA_EINVAL;
     if (10 * (size_t)x->c * 4 > 60 * 1024) return ISA_EINVAL;
@@ -334,7 +354,9 @@ extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, cons
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldd = dy->ld;
     p.pro = make_pro(pro);
     p.csrc = (csrc > 0 && csrc < x->c) ? csrc : x->c;
+    if (!ws) return ISA_EINVAL;
+    p.ws = ws;
     const bool has_pro = !pro_trivial(p.pro);
-    if (x->dtype == ISA_BF16) return launch_wg<bf16_t, 8>(p, has_pro, as_stream(stream));
-    return launch_wg<float, 4>(p, has_pro, as_stream(stream));
+    if (x->dtype == ISA_BF16) return launch_wg<bf16_t, 8>(p, has_pro, ws_floats, as_stream(stream));
+    return launch_wg<float, 4>(p, has_pro, ws_floats, as_stream(stream));
 }

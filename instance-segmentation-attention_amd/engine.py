@@ -517,8 +517,8 @@ class Engine:
                 dy = self.grads.grad_of(out)
                 L.check(self.lib.isa_dwconv3x3_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                      self.params.gptr(bias) if bias else None,
-                                                     self.params.shapes[wname][0], self.st()),
-                        "isa_dwconv3x3_wgrad")
+                                                     self.params.shapes[wname][0], L.ptr(self.ws), self.ws.numel(),
+                                                     self.st()), "isa_dwconv3x3_wgrad")
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
                     L.check(self.lib.isa_dwconv3x3_dgrad(dy.d(), self.packer.ptr(reg["dgrad"]),
