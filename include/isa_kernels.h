@@ -238,6 +238,19 @@ int isa_sqnorm(const float* g, int64_t n, float scale, float* out /*zeroed*/, vo
 int isa_adadelta(float* p, const float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps, float wd,
                  const float* sqnorm, float max_norm, float gscale, void* stream);
 
+/* ---- the reference's named attention operators (modules/utils.py; dead at HEAD) --
+ * a19 ScaledDotProductAttention.forward (utils.py:316-327): out[bh,lq,dv] = softmax(mask(q k^T / T)) v,
+ *     attn[bh,lq,L] optional.  q[bh,lq,dk] k[bh,L,dk] v[bh,L,dv] contiguous, dtype ISA_F32|ISA_BF16;
+ *     mask[bh,lq,L] bytes, non-zero = masked.  K/V are streamed once (online softmax, LDS-staged tiles). */
+int isa_sdp_attention(const void* q, const void* k, const void* v, const uint8_t* mask, void* out,
+                      float* attn, int32_t bh, int32_t lq, int64_t L, int32_t dk, int32_t dv,
+                      float temperature, int32_t dtype, void* stream);
+/* a20 _ScalePDAttention core (utils.py:276-299): per-pixel softmax over the 3x3 neighbourhood at `dilation` */
+int isa_local_attention(const isa_tensor* q, const isa_tensor* k, const isa_tensor* v, const float* nomask,
+                        const isa_tensor* out, int32_t dilation, void* stream);
+/* a21 Decoder.forward (utils.py:59-69): out[b,p] = sigmoid(<q[b,:], enc[b,p,:]>) */
+int isa_point_query(const float* q, const isa_tensor* enc, float* out, void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);
