@@ -1,0 +1,52 @@
+"""Synthetic stand-in for the LMDB dataset + AlignCollate output (dataset.py:368-378): the reference
+ships no data.  Same tensors and dtypes the collate function produces; rectangles/ellipses as instances
+(mirrors the zero-padded 32-instance layout, dataset.py:304-310).  numpy RNG only."""
+import numpy as np
+import torch
+
+
+def synth_batch(batch, height, width, seed=0, max_objects=32, kmin=3, kmax=8):
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((batch, 21, height, width)).astype(np.float32)
+    ins = np.zeros((batch, max_objects, height, width), dtype=np.int64)
+    n = np.zeros((batch,), dtype=np.int32)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for b in range(batch):
+        k = int(rs.randint(kmin, kmax + 1))
+        occupied = np.zeros((height, width), dtype=bool)
+        placed = tries = 0
+        while placed < k and tries < 200:
+            tries += 1
+            hh = int(rs.randint(max(2, height // 10), max(3, height // 3)))
+            ww = int(rs.randint(max(2, width // 10), max(3, width // 3)))
+            y0, x0 = int(rs.randint(0, height - hh + 1)), int(rs.randint(0, width - ww + 1))
+            if rs.rand() < 0.5:
+                m = (yy >= y0) & (yy < y0 + hh) & (xx >= x0) & (xx < x0 + ww)
+            else:
+                cy, cx = y0 + hh / 2.0, x0 + ww / 2.0
+                m = ((yy + 0.5 - cy) / (hh / 2.0)) ** 2 + ((xx + 0.5 - cx) / (ww / 2.0)) ** 2 <= 1.0
+            if m.sum() < 4 or (m & occupied).any():
+                continue
+            ins[b, placed][m] = 1
+            occupied |= m
+            placed += 1
+        n[b] = placed
+        x[b, :3] += occupied[None].astype(np.float32)
+    fg = ins.sum(1) > 0
+    sem = np.stack([~fg, fg], 1).astype(np.int64)
+    return torch.from_numpy(x), torch.from_numpy(sem), torch.from_numpy(ins), torch.from_numpy(n)
+
+
+class SyntheticLoader(object):
+    """Iterable of `n_batches` collated minibatches, re-seeded per epoch like a shuffling DataLoader."""
+
+    def __init__(self, n_batches, batch_size, height=256, width=256, seed=0):
+        self.n, self.bs, self.h, self.w, self.seed, self.epoch = n_batches, batch_size, height, width, seed, 0
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        self.epoch += 1
+        for i in range(self.n):
+            yield synth_batch(self.bs, self.h, self.w, seed=self.seed + 1000 * self.epoch + i)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""train.py — entry point with the reference's flags (code/train.py:18-37) on the MI355X engine.
+The reference trains from an LMDB that is not in its repository; this runs the same loop on synthetic
+collated batches (data.py) unless a loader is plugged in.  Hyper-parameters: settings/CVPPP/training_settings.py."""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import isa_amd  # noqa: F401,E402
+from isa_amd.model import Model  # noqa: E402
+from isa_amd.data import SyntheticLoader  # noqa: E402
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--model', default='', help="Filepath of trained model (to continue training) [Default: '']")
+parser.add_argument('--usegpu', action='store_true', default=True, help='Enables the GPU [always on in this build]')
+parser.add_argument('--nepochs', type=int, default=800, help='Number of epochs to train for [Default: 800]')
+parser.add_argument('--batchsize', type=int, default=2, help='Batch size [Default: 2]')
+parser.add_argument('--debug', action='store_true', help='Activates debug mode [Default: False]')
+parser.add_argument('--nworkers', type=int, default=2, help='accepted for compatibility (synthetic data needs none)')
+parser.add_argument('--dataset', type=str, default='CVPPP', help='Name of the dataset which is "CVPPP"')
+parser.add_argument('--iters-per-epoch', type=int, default=8)
+parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+parser.add_argument('--out', default=os.path.join(ROOT, 'models', 'CVPPP', 'run'))
+opt = parser.parse_args()
+assert opt.dataset in ['CVPPP', ]
+
+SEED = 23                                                     # training_settings.py:53
+random.seed(SEED); np.random.seed(SEED); torch.manual_seed(SEED)
+model = Model(opt.dataset, 'ReSeg', 2, 32, use_instance_segmentation=True, load_model_path=opt.model, usegpu=True,
+              dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32)
+train_loader = SyntheticLoader(opt.iters_per_epoch, opt.batchsize, 256, 256, seed=SEED)
+test_loader = SyntheticLoader(max(1, opt.iters_per_epoch // 4), opt.batchsize, 256, 256, seed=SEED + 7)
+model.fit('Multi', 0.5, 1.5, 2, 1.0, 0.001, 10.0, 0.5, 25, False, 'Adadelta', True, opt.nepochs, None,
+          train_loader, test_loader, opt.out, opt.debug)
