@@ -29,6 +29,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s meas
 ALG_BYTES_PER_IMAGE_BF16 = {"infer": 161.7e6, "train_fwd": 1.071e9, "train_step": 3.2e9}
 
 
+def load_traffic(entry_point):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_traffic.json,
+    collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs and the gfx950 x2 FETCH
+    correction of MI355X_MICROARCH.md).  null when no committed measurement covers that kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if entry_point in d:
+                return d[entry_point]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +163,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": name, "launches_per_step": calls,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(name),
                 "avg_launch_us": round(tot_ms * 1e3 / calls, 2),
                 "alg_bytes_per_launch": int(nbytes / calls),
                 "step_frac": round(value / world * step_bytes / 1e9 / HBM_PEAK_GBS, 4),

@@ -479,6 +479,8 @@ class Engine:
                                                        dx.d(), L.IN_GATHER2, L.OUT_PLAIN, None, acc, self.st()),
                                 "isa_conv_gemm(dgradT)")
                     else:
+                        if self.profile:
+                            self.next_bytes = (dy.n * dy.h * dy.w * dy.c + dx.n * dx.h * dx.w * dx.c) * dy.buf.element_size()
                         L.check(self.lib.isa_conv_gemm(dy.d(), None, pk.ptr(reg["dgrad"]), reg["kp_d"], None,
                                                        dx.d(), in_mode, L.OUT_PLAIN, None, acc, self.st()),
                                 "isa_conv_gemm(dgrad)")
@@ -515,12 +517,16 @@ class Engine:
         if self.record:
             def bwd():
                 dy = self.grads.grad_of(out)
+                if self.profile:
+                    self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
                 L.check(self.lib.isa_dwconv3x3_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                      self.params.gptr(bias) if bias else None,
                                                      self.params.shapes[wname][0], L.ptr(self.ws), self.ws.numel(),
                                                      self.st()), "isa_dwconv3x3_wgrad")
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
+                    if self.profile:
+                        self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
                     L.check(self.lib.isa_dwconv3x3_dgrad(dy.d(), self.packer.ptr(reg["dgrad"]),
                                                          self.grads.grad_of(x).d(), acc, self.st()),
                             "isa_dwconv3x3_dgrad")
@@ -556,10 +562,15 @@ class Engine:
         b = lazy.bn
         P = self.params
         red = self.scratch(2 * lazy.c * STAT_R) if b["train"] else None
+        nb = lazy.n * lazy.h * lazy.w * lazy.c * lazy.buf.element_size()
         if b["train"]:
+            if self.profile:
+                self.next_bytes = 2 * nb
             L.check(self.lib.isa_bn_bwd_reduce(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
                                                L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),
                                                L.ptr(red), self.st()), "isa_bn_bwd_reduce")
+        if self.profile:
+            self.next_bytes = 3 * nb
         L.check(self.lib.isa_bn_bwd_apply(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
                                           L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),
                                           P.ptr(b["pre"] + ".weight"), L.ptr(red), b["count"], 1 if b["train"] else 0,
@@ -584,6 +595,8 @@ class Engine:
         lazy = raw.with_pro(Pro(scale, shift, act, bscale))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
+        if self.profile:
+            self.next_bytes = (2 + (res is not None) + (res2 is not None)) * raw.n * raw.h * raw.w * raw.c * raw.buf.element_size()
         L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), res.d() if res is not None else None,
                                             res2.d() if res2 is not None else None, L.ptr(oscale), out.d(),
                                             self.st()), "isa_affine_act_res")
