@@ -116,6 +116,31 @@ int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const isa_tensor* d
 int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                         float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, void* stream);
 
+/* Backward constants of one train-mode BatchNorm2d layer (what torch autograd keeps for
+ * native_batch_norm_backward): scale/shift/mean/invstd from isa_bn_finalize, `red` = the
+ * [ISA_STAT_REPLICAS][2C] sums written by isa_bn_bwd_reduce (folded in place by the consumer),
+ * `out_red` = where a fused producer writes those sums, dgamma/dbeta accumulate (may be NULL).     */
+typedef struct isa_bn_bwd {
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    float* red; float* out_red;
+    float* dgamma; float* dbeta;
+    float count; int32_t act;
+} isa_bn_bwd;
+
+/* Fused backward of the  x -> dw3x3 -> y -> BN(train)+act  segment of InvertedResidual /
+ * InvertedV1Residual (MobileNetDenseASPP.py:77-80,109-111), one pass over HBM:
+ *   dy   = BN-backward(g, y; ybn)                 (what isa_bn_bwd_apply would store)
+ *   dx  (+)= dw3x3^T(dy),  dw += pro(x) (*) dy    (isa_dwconv3x3_dgrad + isa_dwconv3x3_wgrad)
+ *   xbn != NULL: xbn->out_red += sums of BN(x)'s backward over the finished dx
+ *                (isa_bn_bwd_reduce of the layer that produced x; requires dx to be complete, i.e.
+ *                every other consumer of x has already accumulated into it).
+ * g, y, x, dx: same shape and dtype, C % 8 == 0; xpro without bscale; ybn->red already reduced.     */
+int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
+                              const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
+                              const void* w_flipped, float* dw, int32_t csrc,
+                              const isa_tensor* dx, int32_t accumulate,
+                              float* ws, int64_t ws_floats, void* stream);
+
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the
  * backward); updates running_mean/var (momentum, unbiased var) when running_* != NULL.

@@ -13,6 +13,12 @@
 //     are combined per workgroup with LDS float atomics, then one global atomic per channel.
 #include "common.hpp"
 
+// LDS-tiled v2 (dwconv_tiled.hip): taken whenever the channel count is a multiple of 8
+int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const float* bias, const isa_tensor* y,
+                float* stats, int accumulate, void* stream);
+int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, float* dw, float* dbias, int csrc,
+              float* ws, long ws_floats, void* stream);
+
 namespace {
 
 constexpr int STRIP = 16;
@@ -299,6 +305,7 @@ int dw_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const flo
                const isa_tensor* y, float* stats, int accumulate, void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(y, 8) || !w || x->dtype != y->dtype) return ISA_EINVAL;
     if (x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) return ISA_EINVAL;
+    if (x->c % 8 == 0) return dw2_forward(x, pro, w, bias, y, stats, accumulate, stream);
     DwParams p{};
     p.x = x->data; p.w = w; p.bias = bias; p.y = y->data;
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldy = y->ld;
@@ -348,6 +355,8 @@ extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, cons
                                    void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (x->n != dy->n || x->h != dy->h || x->w != dy->w || x->c != dy->c) return ISA_EINVAL;
+    if (!ws) return ISA_EINVAL;
+    if (x->c % 8 == 0) return dw2_wgrad(x, pro, dy, dw, dbias, csrc, ws, ws_floats, stream);
     if (10 * (size_t)x->c * 4 > 60 * 1024) return ISA_EINVAL;
     DwWgParams p{};
     p.x = x->data; p.dy = dy->data; p.dw = dw; p.dbias = dbias;

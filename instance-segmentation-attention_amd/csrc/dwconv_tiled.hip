@@ -1,0 +1,671 @@
+// Depthwise 3x3 v2: LDS-staged halo tiles.  (v1 in dwconv.hip walks row strips with a register window; PMC
+// showed it latency-bound: 62 % SQ_WAIT_ANY at 2 waves/SIMD with 3 dependent loads per column.)
+//   * a workgroup owns an 8 x 32 output tile x 32 channels.  The (8+2) x (32+2) input halo is staged ONCE
+//     in LDS as fp32 after the lazy BN/ReLU6 prologue: every lane issues its 5-6 independent 16-byte
+//     loads back to back, so ~24 KB per workgroup is in flight instead of 3 loads per wave.
+//   * compute: lane = (8-channel group, 4 consecutive x): 18 row vectors from LDS feed 36 FMA-vectors for
+//     4 outputs (horizontal register reuse), pixel stride padded to 36 floats so the four x-groups of a
+//     16-lane ds_read_b128 group land on disjoint banks.
+//   * forward/dgrad: bias, next-BN statistics (16-lane shuffle tree, then 4 LDS atomics per wave, then one
+//     global atomic per channel into the replicated buffer), optional read-modify-write accumulate.
+//   * wgrad: persistent over tiles of one channel block; 9x8 products per lane accumulated in registers
+//     across tiles, reduced once (shuffle tree + LDS) into a per-workgroup slab (no global atomics).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, CB = 32, PS = 36;         // tile rows/cols, channel block, pixel stride (floats)
+constexpr int HALO = (TH + 2) * (TW + 2);
+
+struct Dw2Params {
+    const void* x; const void* w; const float* bias; void* y; const void* dy;
+    int n, h, w_, c, ldx, ldy, ldd, wld;
+    ProDev pro;
+    float* stats; int accumulate;
+    int tiles_x, tiles_y; long ntiles;
+    float* ws; int csrc;
+};
+
+// per-lane prologue constants: a lane stages the same 8-channel group on every iteration (i += 256 keeps i & 3)
+struct ProRegs { float sc[8], sh[8], bs[8]; };
+
+template <bool HAS_PRO>
+__device__ __forceinline__ void load_pro(const Dw2Params& p, ProRegs& r, int c0, int b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = min(c0 + j, p.c - 1);
+        r.sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
+        r.sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
+        r.bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + c] : 1.f;
+    }
+}
+
+template <typename T, bool HAS_PRO, int ACT>
+__device__ __forceinline__ void stage_tile(const Dw2Params& p, const ProRegs& r, float* tile, int b, int ty, int tx, int c_base) {
+    const T* xin = reinterpret_cast<const T*>(p.x);
+    const int cg = threadIdx.x & 3;
+    const int c0 = c_base + cg * 8;
+    const bool cok = c0 < p.c;
+    constexpr int NIT = (HALO * 4 + 255) / 256;
+    float v[NIT][8];
+    bool ok[NIT];
+    // all global loads first (independent, in flight together), then prologue + LDS stores
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pix = (threadIdx.x + it * 256) >> 2;
+        const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+        const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
+        ok[it] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
+        if (ok[it]) load8<T>(xin + (((long)b * p.h + gy) * p.w_ + gx) * p.ldx + c0, v[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pix = (threadIdx.x + it * 256) >> 2;
+        if (pix >= HALO) continue;
+        f32x4 a, bb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = 0.f;
+            if (ok[it]) {
+                z = v[it][j];
+                if constexpr (HAS_PRO) {
+                    z = act_t<ACT>(fmaf(z, r.sc[j], r.sh[j]), p.pro.act);
+                    if (p.pro.bscale) z *= r.bs[j];
+                }
+            }
+            if (j < 4) a[j] = z; else bb[j - 4] = z;
+        }
+        *reinterpret_cast<f32x4*>(tile + pix * PS + cg * 8) = a;
+        *reinterpret_cast<f32x4*>(tile + pix * PS + cg * 8 + 4) = bb;
+    }
+}
+
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+
+template <typename T, bool HAS_PRO, int ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dw2_fwd_kernel(Dw2Params p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* tile = sm;                       // [HALO][PS]
+    float* wts = sm + HALO * PS;            // [9][CB]
+    float* red = wts + 9 * CB;              // [2*CB]
+    const int tid = threadIdx.x;
+    const int c_base = blockIdx.y * CB;
+    const long t = blockIdx.x;
+    const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+    const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+    const T* wp = reinterpret_cast<const T*>(p.w);
+    for (int i = tid; i < 9 * CB; i += 256) {
+        const int tp = i / CB, cc = i - tp * CB;
+        wts[i] = (c_base + cc < p.c) ? st<T>::ld(wp + (long)tp * p.wld + c_base + cc) : 0.f;
+    }
+    if (tid < 2 * CB) red[tid] = 0.f;
+    ProRegs pr;
+    load_pro<HAS_PRO>(p, pr, c_base + (tid & 3) * 8, b);
+    stage_tile<T, HAS_PRO, ACT>(p, pr, tile, b, ty, tx, c_base);
+    __syncthreads();
+
+    const int cg = tid & 3, g = tid >> 2, row = g >> 3, x0 = (g & 7) * 4;
+    const int c0 = c_base + cg * 8;
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[o][j] = (p.bias && c0 + j < p.c) ? p.bias[c0 + j] : 0.f;
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy) {
+        float wr[3][8], in[6][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ld8(wts + (dy * 3 + k) * CB + cg * 8, wr[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ld8(tile + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(in[o + k][j], wr[k][j], acc[o][j]);
+    }
+    const int oy = ty * TH + row;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (oy < p.h && c0 < p.c) {
+        T* yout = reinterpret_cast<T*>(p.y);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int ox = tx * TW + x0 + o;
+            if (ox >= p.w_) continue;
+            T* dst = yout + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
+            if (p.accumulate) {
+                float old[8]; load8<T>(dst, old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] += old[j];
+            }
+            store8<T>(dst, acc[o]);
+        }
+    }
+    if (p.stats) {
+        // lanes with equal (lane & 3) share a channel group: fold the 16 of them, then 4 LDS atomics per wave
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+        }
+        if ((tid & 63) < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&red[cg * 8 + j], s1[j]); atomicAdd(&red[CB + cg * 8 + j], s2[j]); }
+        }
+        __syncthreads();
+        if (tid < 2 * CB) {
+            const int cc = tid & (CB - 1), which = tid / CB;
+            if (c_base + cc < p.c && red[tid] != 0.f) {
+                float* rep = p.stats + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
+                atomicAdd(rep + which * p.c + c_base + cc, red[tid]);
+            }
+        }
+    }
+}
+
+// wgrad: slab[blockIdx.x][t*CB + cc] (t < 9) and [9*CB + cc] (bias) for channel block blockIdx.y
+template <typename T, bool HAS_PRO, int ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw2_wgrad_kernel(Dw2Params p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* tile = sm;                       // [HALO][PS]
+    float* red = sm + HALO * PS;            // [10*CB]
+    const int tid = threadIdx.x;
+    const int c_base = blockIdx.y * CB;
+    const int cg = tid & 3, g = tid >> 2, row = g >> 3, x0 = (g & 7) * 4;
+    const int c0 = c_base + cg * 8;
+    const T* din = reinterpret_cast<const T*>(p.dy);
+    float acc[9][8], db[8];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) db[j] = 0.f;
+    for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+        ProRegs pr;
+        load_pro<HAS_PRO>(p, pr, c0, b);
+        __syncthreads();
+        stage_tile<T, HAS_PRO, ACT>(p, pr, tile, b, ty, tx, c_base);
+        // this lane's four output gradients straight from global, issued once the staging registers are free;
+        // they stay in flight across the barrier
+        float d[4][8];
+        const int oy = ty * TH + row;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int ox = tx * TW + x0 + o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[o][j] = 0.f;
+            if (oy < p.h && ox < p.w_ && c0 < p.c) load8<T>(din + (((long)b * p.h + oy) * p.w_ + ox) * p.ldd + c0, d[o]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) db[j] += d[o][j];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            float in[6][8];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ld8(tile + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[dy * 3 + k][j] = fmaf(in[o + k][j], d[o][j], acc[dy * 3 + k][j]);
+            __builtin_amdgcn_sched_barrier(0);       // keep one row of LDS reads live at a time (register budget)
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 10 * CB; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int tp = 0; tp < 10; ++tp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = tp < 9 ? acc[tp < 9 ? tp : 0][j] : db[j];
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+        }
+    }
+    __syncthreads();
+    float* slab = p.ws + ((long)blockIdx.x * gridDim.y + blockIdx.y) * 10 * CB;
+    for (int i = tid; i < 10 * CB; i += 256) slab[i] = red[i];
+}
+
+constexpr int DW2_RSPLIT = 16;
+// dw[c][t] += sum_b slab[b][cb][t*CB+cc]; dbias[c] += slab[...][9*CB+cc]
+__global__ __launch_bounds__(256) void dw2_wgrad_reduce_kernel(const float* ws, int nblk, int ncb, int C, int csrc, float* dw, float* dbias) {
+    const int cb = blockIdx.x, split = blockIdx.y;
+    const int per = (nblk + DW2_RSPLIT - 1) / DW2_RSPLIT;
+    const int b0 = split * per, b1 = min(nblk, b0 + per);
+    if (b0 >= b1) return;
+    for (int i = threadIdx.x; i < 10 * CB; i += 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += ws[((long)b * ncb + cb) * 10 * CB + i];
+        const int tp = i / CB, c = cb * CB + (i - tp * CB);
+        if (c >= csrc || c >= C) continue;
+        if (tp < 9) atomicAdd(dw + c * 9 + tp, s);
+        else if (dbias) atomicAdd(dbias + c, s);
+    }
+}
+
+template <typename T>
+int launch_fwd2(Dw2Params& p, bool has_pro, hipStream_t s) {
+    p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
+    if (p.ntiles >= (1L << 31)) return ISA_EINVAL;
+    dim3 grid((unsigned)p.ntiles, (p.c + CB - 1) / CB);
+    const size_t lds = ((size_t)HALO * PS + 9 * CB + 2 * CB) * 4;
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw2_fwd_kernel<T, true, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((dw2_fwd_kernel<T, true, ACT_RT>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dw2_fwd_kernel<T, false, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
+    return launch_status();
+}
+
+template <typename T>
+int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, hipStream_t s) {
+    p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
+    const int ncb = (p.c + CB - 1) / CB;
+    long gx = (256L * 2) / ncb;          // 2 resident workgroups per CU
+    if (gx < 1) gx = 1;
+    if (gx > p.ntiles) gx = p.ntiles;
+    const long ws_cap = ws_floats / (10L * CB * ncb);
+    if (ws_cap < 1) return ISA_EINVAL;
+    if (gx > ws_cap) gx = ws_cap;
+    dim3 grid((unsigned)gx, ncb);
+    const size_t lds = ((size_t)HALO * PS + 10 * CB) * 4;
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ACT_RT>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dw2_wgrad_kernel<T, false, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, (float*)p.y, (float*)p.bias);
+    return launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward of  x --dw3x3--> y --BN(train)+act--> ...   (InvertedResidual / InvertedV1Residual middle):
+//   given g = dL/d act(BN(y)) and the already reduced sums of BN(y)'s backward, one pass over the tiles does
+//     1. dy = gamma*invstd*(g*act'(z) - mean(g') - yhat*mean(g'*yhat))   (the BN-backward "apply", never stored)
+//     2. dx (+)= dw3x3_flipped(dy)                                          (depthwise data gradient)
+//     3. dW += sum  pro(x)[window] * dy                                     (depthwise weight gradient)
+//     4. if x is itself a lazy BN output: the sums (sum g_x, sum g_x*xhat) its BN backward needs, from the
+//        dx tile still in registers                                         (the next BN-backward "reduce")
+//   replacing bn_bwd_apply (3 tensor passes) + dw_wgrad (2) + dw_dgrad (2) + bn_bwd_reduce (2) by
+//   3 reads + 1 write.  dy is rounded to the storage type in LDS exactly as the unfused path rounds it in HBM.
+struct FusedParams {
+    const void *g, *y, *x, *w; void* dx;
+    int n, h, w_, c, ldg, ldy, ldx, lddx, wld;
+    const float *ysc, *ysh, *ymu, *yis, *yred; float ycnt_inv; int yact; float *ydgamma, *ydbeta;
+    const float *xsc, *xsh, *xmu, *xis; int xact; float* xred;
+    int accumulate, tiles_x, tiles_y; long ntiles; float* ws; int csrc; float* dw;
+};
+
+
+// 8 storage elements kept packed in registers (4 VGPRs for bf16) until they are consumed
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
+};
+template <> struct raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+
+template <typename T> struct dd_stride { static constexpr int v = 36; };       // floats: 144 B / pixel
+template <> struct dd_stride<bf16_t> { static constexpr int v = 40; };         // 80 B / pixel: 4 x-groups tile 256 B
+
+__global__ void collapse8_kernel(float* red, int n2c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2c; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < ISA_STAT_R; ++r) s += red[r * n2c + i];
+        red[i] = s;
+    }
+}
+
+// XMODE 0: x is a plain tensor; 1: x = relu6(BN(x_raw)) and its backward sums are produced;
+//       2: x has a runtime prologue, sums produced when p.xred != null
+template <typename T, int YACT, int XMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_bn_bwd_kernel(FusedParams p) {
+    constexpr int PSD = dd_stride<T>::v;
+    constexpr int XACT = XMODE == 1 ? ISA_ACT_RELU6 : (XMODE == 0 ? ISA_ACT_NONE : ACT_RT);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xt = sm;                                              // [HALO][PS]  pro(x), fp32
+    T* dt = reinterpret_cast<T*>(sm + HALO * PS);                // [HALO][PSD] dy, storage type
+    float* wts = reinterpret_cast<float*>(dt + HALO * PSD);      // [9][CB] flipped taps
+    float* cst = wts + 9 * CB;                                   // [10][CB] per-channel constants
+    float* red = cst + 10 * CB;                                  // [10*CB]
+    const int tid = threadIdx.x;
+    const int c_base = blockIdx.y * CB;
+    const int cg = tid & 3, g4 = tid >> 2, row = g4 >> 3, x0 = (g4 & 7) * 4;
+    const int c0 = c_base + cg * 8;
+    const bool cok = c0 < p.c;
+    const T* wp = reinterpret_cast<const T*>(p.w);
+    for (int i = tid; i < 9 * CB; i += 256) {
+        const int tp = i / CB, cc = i - tp * CB;
+        wts[i] = (c_base + cc < p.c) ? st<T>::ld(wp + (long)tp * p.wld + c_base + cc) : 0.f;
+    }
+    if (tid < CB) {
+        const int c = min(c_base + tid, p.c - 1);
+        cst[0 * CB + tid] = p.ysc[c]; cst[1 * CB + tid] = p.ysh[c];
+        cst[2 * CB + tid] = p.ymu[c]; cst[3 * CB + tid] = p.yis[c];
+        cst[4 * CB + tid] = p.yred[c] * p.ycnt_inv; cst[5 * CB + tid] = p.yred[p.c + c] * p.ycnt_inv;
+        cst[6 * CB + tid] = (XMODE && p.xsc) ? p.xsc[c] : 1.f; cst[7 * CB + tid] = (XMODE && p.xsh) ? p.xsh[c] : 0.f;
+        cst[8 * CB + tid] = (XMODE && p.xmu) ? p.xmu[c] : 0.f; cst[9 * CB + tid] = (XMODE && p.xis) ? p.xis[c] : 1.f;
+        if (blockIdx.x == 0 && c_base + tid < p.c) {             // BN(y) parameter gradients: dbeta = sum g', dgamma = sum g'*yhat
+            if (p.ydgamma) atomicAdd(p.ydgamma + c, p.yred[p.c + c]);
+            if (p.ydbeta) atomicAdd(p.ydbeta + c, p.yred[c]);
+        }
+    }
+    float acc[9][8], s0[8], s1[8];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    const T* gin = reinterpret_cast<const T*>(p.g);
+    const T* yin = reinterpret_cast<const T*>(p.y);
+    const T* xin = reinterpret_cast<const T*>(p.x);
+    T* dxo = reinterpret_cast<T*>(p.dx);
+    constexpr int NIT = (HALO * 4 + 255) / 256;
+    constexpr int NB = 3;
+    static_assert(NIT % NB == 0, "staging chunks");
+    const bool want_xred = XMODE == 1 || (XMODE == 2 && p.xred != nullptr);
+
+    for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+        __syncthreads();                                         // constants visible / previous tile fully consumed
+        {   // ---- stage dy = BN-backward(g, y) with halo, NB vectors per lane at a time
+            float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
+            ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
+            ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
+#pragma unroll
+            for (int it0 = 0; it0 < NIT; it0 += NB) {
+                raw8<T> gv[NB], yv[NB]; bool ok[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+                    const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
+                    ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
+                    if (ok[u]) {
+                        const long po = ((long)b * p.h + gy) * p.w_ + gx;
+                        gv[u].load(gin + po * p.ldg + c0);
+                        yv[u].load(yin + po * p.ldy + c0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    if (pix >= HALO) continue;
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = 0.f;
+                        if (ok[u]) {
+                            const float yy = yv[u].get(j);
+                            const float z = fmaf(yy, sc[j], sh[j]);
+                            const float dz = gv[u].get(j) * act_grad_t<YACT>(z, p.yact);
+                            const float yh = (yy - mu[j]) * is[j];
+                            v = sc[j] * (dz - k0[j] - yh * k1[j]);
+                        }
+                        o[j] = v;
+                    }
+                    store8<T>(dt + pix * PSD + cg * 8, o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {   // ---- stage pro(x) with halo (fp32)
+            float sc[8], sh[8];
+            ld8(cst + 6 * CB + cg * 8, sc); ld8(cst + 7 * CB + cg * 8, sh);
+#pragma unroll
+            for (int it0 = 0; it0 < NIT; it0 += NB) {
+                raw8<T> xv[NB]; bool ok[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+                    const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
+                    ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
+                    if (ok[u]) xv[u].load(xin + (((long)b * p.h + gy) * p.w_ + gx) * p.ldx + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    if (pix >= HALO) continue;
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = 0.f;
+                        if (ok[u]) v = XMODE ? act_t<XACT>(fmaf(xv[u].get(j), sc[j], sh[j]), p.xact) : xv[u].get(j);
+                        o[j] = v;
+                    }
+                    store8<float>(xt + pix * PS + cg * 8, o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        const int oy = ty * TH + row;
+        {   // ---- data gradient: dx tile = flipped taps over dy (halo), then BN(x)-backward sums
+            float a[4][8];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[o][j] = 0.f;
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                float wr[3][8], in[6][8];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ld8(wts + (dy * 3 + k) * CB + cg * 8, wr[k]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) load8<T>(dt + ((row + dy) * (TW + 2) + x0 + k) * PSD + cg * 8, in[k]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[o][j] = fmaf(in[o + k][j], wr[k][j], a[o][j]);
+            }
+            if (oy < p.h && cok) {
+                float xs[8], xh[8], xm[8], xi[8];
+                if (want_xred) {
+                    ld8(cst + 6 * CB + cg * 8, xs); ld8(cst + 7 * CB + cg * 8, xh);
+                    ld8(cst + 8 * CB + cg * 8, xm); ld8(cst + 9 * CB + cg * 8, xi);
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int ox = tx * TW + x0 + o;
+                    if (ox >= p.w_) continue;
+                    const long po = ((long)b * p.h + oy) * p.w_ + ox;
+                    T* dst = dxo + po * p.lddx + c0;
+                    if (p.accumulate) {
+                        float old[8]; load8<T>(dst, old);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[o][j] += old[j];
+                    }
+                    store8<T>(dst, a[o]);
+                    if (want_xred) {
+                        // the unfused reduce reads the stored (rounded) gradient: round the same way
+                        float xr[8]; load8<T>(xin + po * p.ldx + c0, xr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float gq = (float)(T)a[o][j];
+                            const float z = fmaf(xr[j], xs[j], xh[j]);
+                            const float dz = gq * act_grad_t<XACT>(z, p.xact);
+                            s0[j] += dz; s1[j] += dz * ((xr[j] - xm[j]) * xi[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // ---- weight gradient: 9 x 8 products per lane, dy centre x pro(x) window
+            float d[4][8];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) load8<T>(dt + ((row + 1) * (TW + 2) + x0 + 1 + o) * PSD + cg * 8, d[o]);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float in[6][8];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ld8(xt + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[dy * 3 + k][j] = fmaf(in[o + k][j], d[o][j], acc[dy * 3 + k][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 10 * CB; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[tp][j];
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+        }
+    }
+    __syncthreads();
+    float* slab = p.ws + ((long)blockIdx.x * gridDim.y + blockIdx.y) * 10 * CB;
+    for (int i = tid; i < 10 * CB; i += 256) slab[i] = red[i];
+    if (want_xred) {
+        __syncthreads();
+        if (tid < 2 * CB) red[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v0 = s0[j], v1 = s1[j];
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
+            if ((tid & 63) < 4) { atomicAdd(&red[cg * 8 + j], v0); atomicAdd(&red[CB + cg * 8 + j], v1); }
+        }
+        __syncthreads();
+        if (tid < 2 * CB) {
+            const int cc = tid & (CB - 1), which = tid / CB;
+            if (c_base + cc < p.c && red[tid] != 0.f) {
+                float* rep = p.xred + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
+                atomicAdd(rep + which * p.c + c_base + cc, red[tid]);
+            }
+        }
+    }
+}
+
+template <typename T, int YACT, int XMODE>
+int launch_fused_inst(FusedParams& p, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)HALO * PS * 4 + (size_t)HALO * dd_stride<T>::v * sizeof(T) + (9 + 10 + 10) * CB * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bn_bwd_kernel<T, YACT, XMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISA_ELAUNCH;
+        configured = true;
+    }
+    hipLaunchKernelGGL((dw_bn_bwd_kernel<T, YACT, XMODE>), grid, dim3(256), lds, s, p);
+    return ISA_OK;
+}
+
+template <typename T>
+int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
+    p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
+    const int ncb = (p.c + CB - 1) / CB;
+    const int per_cu = sizeof(T) == 2 ? 2 : 1;                   // LDS: 79 KB (bf16) / 100 KB (f32) per workgroup
+    long gx = (256L * per_cu) / ncb;
+    if (gx < 1) gx = 1;
+    if (gx > p.ntiles) gx = p.ntiles;
+    const long ws_cap = ws_floats / (10L * CB * ncb);
+    if (ws_cap < 1) return ISA_EINVAL;
+    if (gx > ws_cap) gx = ws_cap;
+    dim3 grid((unsigned)gx, ncb);
+    hipLaunchKernelGGL(collapse8_kernel, dim3(cdiv(2 * p.c, 256)), dim3(256), 0, s, const_cast<float*>(p.yred), 2 * p.c);
+    int rc;
+    const bool y6 = p.yact == ISA_ACT_RELU6;
+    if (xmode == 0) rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 0>(p, grid, s) : launch_fused_inst<T, ACT_RT, 0>(p, grid, s);
+    else if (xmode == 1) rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 1>(p, grid, s) : launch_fused_inst<T, ACT_RT, 1>(p, grid, s);
+    else rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 2>(p, grid, s) : launch_fused_inst<T, ACT_RT, 2>(p, grid, s);
+    if (rc != ISA_OK) return rc;
+    hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, p.dw, (float*)nullptr);
+    return launch_status();
+}
+
+}  // namespace
+
+// v2 entry points used by dwconv.hip's C-ABI functions when the view allows (C % 8 == 0)
+int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const float* bias, const isa_tensor* y,
+                float* stats, int accumulate, void* stream) {
+    Dw2Params p{};
+    p.x = x->data; p.w = w; p.bias = bias; p.y = y->data;
+    p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldy = y->ld; p.wld = ((x->c + 7) / 8) * 8;
+    p.pro = make_pro(pro); p.stats = stats; p.accumulate = accumulate;
+    const bool has_pro = !pro_trivial(p.pro);
+    if (x->dtype == ISA_BF16) return launch_fwd2<bf16_t>(p, has_pro, as_stream(stream));
+    return launch_fwd2<float>(p, has_pro, as_stream(stream));
+}
+
+int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, float* dw, float* dbias, int csrc,
+              float* ws, long ws_floats, void* stream) {
+    Dw2Params p{};
+    p.x = x->data; p.dy = dy->data; p.y = dw; p.bias = dbias;        // y/bias slots carry the output pointers
+    p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldd = dy->ld;
+    p.pro = make_pro(pro); p.ws = ws; p.csrc = (csrc > 0 && csrc < x->c) ? csrc : x->c;
+    const bool has_pro = !pro_trivial(p.pro);
+    if (x->dtype == ISA_BF16) return launch_wg2<bf16_t>(p, has_pro, ws_floats, as_stream(stream));
+    return launch_wg2<float>(p, has_pro, ws_floats, as_stream(stream));
+}
+
+// Fused BN-apply + depthwise dgrad/wgrad + next BN-reduce; see dw_bn_bwd_kernel.
+extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
+                                         const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
+                                         const void* w_flipped, float* dw, int32_t csrc,
+                                         const isa_tensor* dx, int32_t accumulate,
+                                         float* ws, int64_t ws_floats, void* stream) {
+    if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
+    if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
+    if (!w_flipped || !dw || !ws) return ISA_EINVAL;
+    if (x->c % 8 != 0) return ISA_EINVAL;
+    const isa_tensor* ts[3] = {y, x, dx};
+    for (const isa_tensor* t : ts)
+        if (t->n != g->n || t->h != g->h || t->w != g->w || t->c != g->c || t->dtype != g->dtype) return ISA_EINVAL;
+    const ProDev xp = make_pro(xpro);
+    if (xp.bscale) return ISA_EINVAL;                             // per-image scales are not folded here
+    if (xbn && (!xbn->mean || !xbn->invstd || !xbn->out_red)) return ISA_EINVAL;
+    FusedParams p{};
+    p.g = g->data; p.y = y->data; p.x = x->data; p.w = w_flipped; p.dx = dx->data;
+    p.n = g->n; p.h = g->h; p.w_ = g->w; p.c = g->c; p.ldg = g->ld; p.ldy = y->ld; p.ldx = x->ld; p.lddx = dx->ld;
+    p.wld = ((g->c + 7) / 8) * 8;
+    p.ysc = ybn->scale; p.ysh = ybn->shift; p.ymu = ybn->mean; p.yis = ybn->invstd; p.yred = ybn->red;
+    p.ycnt_inv = 1.f / ybn->count; p.yact = ybn->act; p.ydgamma = ybn->dgamma; p.ydbeta = ybn->dbeta;
+    p.xsc = xp.scale; p.xsh = xp.shift; p.xact = xp.act;
+    p.xmu = xbn ? xbn->mean : nullptr; p.xis = xbn ? xbn->invstd : nullptr; p.xred = xbn ? xbn->out_red : nullptr;
+    p.accumulate = accumulate; p.ws = ws; p.dw = dw;
+    p.csrc = (csrc > 0 && csrc < g->c) ? csrc : g->c;
+    int xmode = 0;
+    if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
+    if (g->dtype == ISA_BF16) return launch_fused<bf16_t>(p, xmode, ws_floats, as_stream(stream));
+    return launch_fused<float>(p, xmode, ws_floats, as_stream(stream));
+}

@@ -10,6 +10,7 @@ lazy prologue).  Multi-consumer tensors accumulate: the first backward writer ov
 writers add (tracked per buffer and channel range) — no memsets of activation-sized buffers.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -375,12 +376,17 @@ class Engine:
         self.profile = False           # when True every launch is bracketed by HIP events
         self.prof_events = []          # (entry point, start event, end event, algorithmic bytes)
         self.next_bytes = 0
+        # fused BN-apply + depthwise backward + next BN-reduce (isa_dwconv3x3_bn_backward); ISA_FUSE_DW_BN=0
+        # selects the separate kernels (A/B measurements, bisecting)
+        self.fuse_dw_bn = os.environ.get("ISA_FUSE_DW_BN", "1") != "0"
+        self._dw_out: Dict[tuple, dict] = {}
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool):
         self.arena.reset()
         self.grads.reset()
         self.tape = []
+        self._dw_out = {}
         self.bn_train, self.record = bn_train, record
         self.stats_cursor = 0
         if self.stats is not None:
@@ -515,10 +521,45 @@ class Engine:
                                        self.params.ptr(bias) if bias else None, out.d(), L.ptr(st), self.st()),
                 "isa_dwconv3x3")
         if self.record:
+            info = None
+            if self.fuse_dw_bn and self.bn_train and x.c % 8 == 0 and bias is None and x.needs_grad \
+                    and (x.pro is None or x.pro.bscale is None):
+                # BN(out)'s backward may leave its "apply" to this conv's backward (see bn()); BN(x)'s
+                # "reduce" can be produced here when that BN was recorded immediately before this conv,
+                # so every other consumer of x has already accumulated its gradient when we run
+                xb = getattr(x, "bn", None)
+                ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
+                info = dict(xbn=xb if ok_x else None, ybn=None)
+                self._dw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
+
             def bwd():
                 dy = self.grads.grad_of(out)
+                nb = x.n * x.h * x.w * x.c * x.buf.element_size()
+                if info is not None and info["ybn"] is not None:
+                    yb, yred = info["ybn"]
+                    xb = info["xbn"]
+                    P = self.params
+                    ydesc = L.IsaBnBwd(L.addr(yb["scale"]), L.addr(yb["shift"]), L.addr(yb["mean"]),
+                                       L.addr(yb["invstd"]), L.addr(yred), None,
+                                       P.gptr(yb["pre"] + ".weight").value, P.gptr(yb["pre"] + ".bias").value,
+                                       yb["count"], yb["act"])
+                    xdesc = None
+                    if xb is not None:
+                        xred = self.scratch(2 * x.c * STAT_R)
+                        xdesc = L.IsaBnBwd(None, None, L.addr(xb["mean"]), L.addr(xb["invstd"]), None,
+                                           L.addr(xred), None, None, xb["count"], xb["act"])
+                        xb["red_done"] = xred
+                    acc = self.grads.claim(x, self)
+                    if self.profile:
+                        self.next_bytes = 4 * nb
+                    L.check(self.lib.isa_dwconv3x3_bn_backward(
+                        dy.d(), yb["raw"].d(), C.byref(ydesc), x.d(), x.p(),
+                        C.byref(xdesc) if xdesc is not None else None, self.packer.ptr(reg["dgrad"]),
+                        self.params.gptr(wname), self.params.shapes[wname][0], self.grads.grad_of(x).d(), acc,
+                        L.ptr(self.ws), self.ws.numel(), self.st()), "isa_dwconv3x3_bn_backward")
+                    return
                 if self.profile:
-                    self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
+                    self.next_bytes = 2 * nb
                 L.check(self.lib.isa_dwconv3x3_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                      self.params.gptr(bias) if bias else None,
                                                      self.params.shapes[wname][0], L.ptr(self.ws), self.ws.numel(),
@@ -526,7 +567,7 @@ class Engine:
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
                     if self.profile:
-                        self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
+                        self.next_bytes = 2 * nb
                     L.check(self.lib.isa_dwconv3x3_dgrad(dy.d(), self.packer.ptr(reg["dgrad"]),
                                                          self.grads.grad_of(x).d(), acc, self.st()),
                             "isa_dwconv3x3_dgrad")
@@ -553,22 +594,35 @@ class Engine:
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
         if self.record:
+            dw = self._dw_out.get((raw.buf.data_ptr(), raw.c0, raw.c)) if train else None
+
             def bwd():
-                self._bn_backward(lazy, self.grads.grad_of(raw), self.grads.grad_of(raw), None)
+                g = self.grads.grad_of(raw)
+                if dw is not None:          # raw came from a depthwise conv: reduce here, apply inside its backward
+                    red = self._bn_backward(lazy, g, g, None, do_apply=False)
+                    dw["ybn"] = (lazy.bn, red)
+                    return
+                self._bn_backward(lazy, g, g, None)
+            lazy.bn["bwd_fn"] = bwd
             self.tape.append(bwd)
         return lazy
 
-    def _bn_backward(self, lazy: Act, dt: Act, dy: Act, bscale):
+    def _bn_backward(self, lazy: Act, dt: Act, dy: Act, bscale, do_apply=True):
+        """reduce (sum g', sum g'*xhat) then apply; `red_done` on the layer means a fused producer
+        already wrote the sums; do_apply=False leaves the apply to a fused consumer and returns them."""
         b = lazy.bn
         P = self.params
-        red = self.scratch(2 * lazy.c * STAT_R) if b["train"] else None
+        red = b.pop("red_done", None)
         nb = lazy.n * lazy.h * lazy.w * lazy.c * lazy.buf.element_size()
-        if b["train"]:
+        if b["train"] and red is None:
+            red = self.scratch(2 * lazy.c * STAT_R)
             if self.profile:
                 self.next_bytes = 2 * nb
             L.check(self.lib.isa_bn_bwd_reduce(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
                                                L.ptr(b["mean"]), L.ptr(b["invstd"]), b["act"], L.ptr(bscale),
                                                L.ptr(red), self.st()), "isa_bn_bwd_reduce")
+        if not do_apply:
+            return red
         if self.profile:
             self.next_bytes = 3 * nb
         L.check(self.lib.isa_bn_bwd_apply(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
@@ -576,6 +630,7 @@ class Engine:
                                           P.ptr(b["pre"] + ".weight"), L.ptr(red), b["count"], 1 if b["train"] else 0,
                                           dy.d(), P.gptr(b["pre"] + ".weight"), P.gptr(b["pre"] + ".bias"),
                                           self.st()), "isa_bn_bwd_apply")
+        return red
 
     def bn_out(self, raw: Act, stats, pre, act, out: Act, res: Optional[Act] = None, bscale=None,
                count=None, res2: Optional[Act] = None, oscale=None) -> Act:

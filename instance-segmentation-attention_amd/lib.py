@@ -29,6 +29,12 @@ class IsaPro(C.Structure):
                 ("act", C.c_int32)]
 
 
+class IsaBnBwd(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("red", C.c_void_p), ("out_red", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("count", C.c_float), ("act", C.c_int32)]
+
+
 class IsaPackEntry(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("kind", C.c_int32),
                 ("n", C.c_int32), ("k", C.c_int32), ("taps", C.c_int32), ("kp", C.c_int32),
@@ -37,6 +43,7 @@ class IsaPackEntry(C.Structure):
 
 P_T, P_PRO, VP, I32, F = C.POINTER(IsaTensor), C.POINTER(IsaPro), C.c_void_p, C.c_int32, C.c_float
 I64 = C.c_int64
+P_BN = C.POINTER(IsaBnBwd)
 
 # name -> argtypes, exactly mirroring include/isa_kernels.h
 SIGNATURES = {
@@ -47,6 +54,7 @@ SIGNATURES = {
     "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],
     "isa_dwconv3x3_dgrad": [P_T, VP, P_T, I32, VP],
     "isa_dwconv3x3_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, VP, I64, VP],
+    "isa_dwconv3x3_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, I32, P_T, I32, VP, I64, VP],
     "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
     "isa_bn_bwd_apply": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP, F, I32, P_T, VP, VP, VP],
@@ -136,6 +144,11 @@ def dtype_code(dt):
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def addr(t):
+    """Device address of a torch tensor as a plain int (None -> NULL) for struct fields."""
+    return None if t is None else t.data_ptr()
 
 
 def stream_ptr():
