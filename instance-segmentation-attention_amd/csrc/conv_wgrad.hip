@@ -17,6 +17,7 @@
 // bf16 storage converts to fp32 while staging; exact-fp32 MFMA keeps weight gradients at fp32 accuracy
 // in both storage modes.  (bf16-MFMA + ds_read_b64_tr_b16 variant: DESIGN.md follow-ups.)
 #include "common.hpp"
+#include "tr_lds.hpp"
 
 namespace {
 
@@ -276,21 +277,6 @@ static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipS
 // verified by scripts/probes/tr_probe.hip).  Row stride is kept == 64 (mod 256) bytes so the four
 // 64-byte row pieces a half-wave touches land on disjoint banks.
 // ---------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-#define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
-
-template <int CH> struct TrStride { static constexpr int bytes = (CH * 2) % 128 == 0 ? CH * 2 + 64 : CH * 2; };
-
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride_bytes, int pix0, int chan0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const char* a = tile + (pix0 + 8 * (g >> 1) + q) * stride_bytes + (chan0 + 16 * (g & 1) + 4 * pp) * 2;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a + 4 * stride_bytes));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 template <int TN, int TK, int ACT>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -602,4 +588,12 @@ extern "C" int isa_colsum(const isa_tensor* x, float* out, void* stream) {
         hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), x->c * 4, as_stream(stream),
                            (const float*)x->data, pixels, x->c, x->ld, out);
     return launch_status();
+}
+
+// second-stage reduction for other translation units that write conv_wgrad-format slabs (conv_fused_bwd.hip)
+int wgrad_slab_reduce_launch(float* ws, float* dw, int gx, int tn, int tk, int N, int cin, hipStream_t s) {
+    WgParams p{};
+    p.ws = ws; p.dw = dw; p.dbias = nullptr; p.kmap = nullptr; p.taps = 1; p.groups_k = 1; p.N = N; p.cin = cin;
+    p.ksrc = cin; p.out_mode = ISA_OUT_PLAIN;
+    return launch_reduce(p, gx, 1, tn, tk, s);
 }

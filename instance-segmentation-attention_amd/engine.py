@@ -380,6 +380,9 @@ class Engine:
         # selects the separate kernels (A/B measurements, bisecting)
         self.fuse_dw_bn = os.environ.get("ISA_FUSE_DW_BN", "1") != "0"
         self._dw_out: Dict[tuple, dict] = {}
+        # the same for bias-free 1x1 convs with <= 64 channels either side (isa_conv1x1_bn_backward, bf16 only)
+        self.fuse_pw_bn = os.environ.get("ISA_FUSE_PW_BN", "1") != "0"
+        self._pw_out: Dict[tuple, dict] = {}
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool):
@@ -387,6 +390,7 @@ class Engine:
         self.grads.reset()
         self.tape = []
         self._dw_out = {}
+        self._pw_out = {}
         self.bn_train, self.record = bn_train, record
         self.stats_cursor = 0
         if self.stats is not None:
@@ -459,7 +463,19 @@ class Engine:
         self._launch_conv(*job)
         self._last_conv = dict(reg=reg, in_mode=in_mode)
         if self.record and record_bwd:
+            info = None
+            if self.fuse_pw_bn and self.bn_train and self.dtype == torch.bfloat16 and taps == 1 and not transposed \
+                    and kmap is None and bias is None and x.needs_grad and out.c <= 64 and x.c <= 64 \
+                    and out.c % 8 == 0 and x.c % 8 == 0 and (x.pro is None or x.pro.bscale is None):
+                xb = getattr(x, "bn", None)
+                ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
+                info = dict(xbn=xb if ok_x else None, ybn=None)
+                self._pw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
+
             def bwd():
+                if info is not None and info["ybn"] is not None:
+                    self._fused_pw_backward(x, wname, info)
+                    return
                 dy = self.grads.grad_of(out)
                 pk = self.packer
                 if transposed:
@@ -492,6 +508,32 @@ class Engine:
                                 "isa_conv_gemm(dgrad)")
             self.tape.append(bwd)
         return out, st
+
+    def _bn_desc(self, b, red=None, out_red=None, with_params=True):
+        P = self.params
+        return L.IsaBnBwd(L.addr(b["scale"]), L.addr(b["shift"]), L.addr(b["mean"]), L.addr(b["invstd"]),
+                          L.addr(red), L.addr(out_red),
+                          P.gptr(b["pre"] + ".weight").value if with_params else None,
+                          P.gptr(b["pre"] + ".bias").value if with_params else None, b["count"], b["act"])
+
+    def _fused_pw_backward(self, x: Act, wname, info):
+        """BN-apply of the conv's output BN + weight gradient + data gradient (+ reduce of the BN that
+        produced x) in one pass: isa_conv1x1_bn_backward."""
+        yb, yred, g = info["ybn"]
+        xb = info["xbn"]
+        ydesc = self._bn_desc(yb, red=yred)
+        xdesc = None
+        if xb is not None:
+            xred = self.scratch(2 * x.c * STAT_R)
+            xdesc = self._bn_desc(xb, out_red=xred, with_params=False)
+            xb["red_done"] = xred
+        acc = self.grads.claim(x, self)
+        if self.profile:
+            self.next_bytes = x.n * x.h * x.w * (2 * g.c + 2 * x.c) * x.buf.element_size()
+        L.check(self.lib.isa_conv1x1_bn_backward(
+            g.d(), yb["raw"].d(), C.byref(ydesc), x.d(), x.p(), C.byref(xdesc) if xdesc is not None else None,
+            self.params.ptr(wname), self.params.gptr(wname), self.grads.grad_of(x).d(), acc,
+            L.ptr(self.ws), self.ws.numel(), self.st()), "isa_conv1x1_bn_backward")
 
     def _launch_conv(self, x, reg, bias, out, in_mode, out_mode, st):
         if self.packer.table is None:
@@ -538,16 +580,11 @@ class Engine:
                 if info is not None and info["ybn"] is not None:
                     yb, yred = info["ybn"]
                     xb = info["xbn"]
-                    P = self.params
-                    ydesc = L.IsaBnBwd(L.addr(yb["scale"]), L.addr(yb["shift"]), L.addr(yb["mean"]),
-                                       L.addr(yb["invstd"]), L.addr(yred), None,
-                                       P.gptr(yb["pre"] + ".weight").value, P.gptr(yb["pre"] + ".bias").value,
-                                       yb["count"], yb["act"])
+                    ydesc = self._bn_desc(yb, red=yred)
                     xdesc = None
                     if xb is not None:
                         xred = self.scratch(2 * x.c * STAT_R)
-                        xdesc = L.IsaBnBwd(None, None, L.addr(xb["mean"]), L.addr(xb["invstd"]), None,
-                                           L.addr(xred), None, None, xb["count"], xb["act"])
+                        xdesc = self._bn_desc(xb, out_red=xred, with_params=False)
                         xb["red_done"] = xred
                     acc = self.grads.claim(x, self)
                     if self.profile:
@@ -594,13 +631,19 @@ class Engine:
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
         if self.record:
-            dw = self._dw_out.get((raw.buf.data_ptr(), raw.c0, raw.c)) if train else None
+            key = (raw.buf.data_ptr(), raw.c0, raw.c)
+            dw = self._dw_out.get(key) if train else None
+            pw = self._pw_out.get(key) if train else None
 
             def bwd():
                 g = self.grads.grad_of(raw)
                 if dw is not None:          # raw came from a depthwise conv: reduce here, apply inside its backward
                     red = self._bn_backward(lazy, g, g, None, do_apply=False)
                     dw["ybn"] = (lazy.bn, red)
+                    return
+                if pw is not None:          # ... or from a small 1x1 conv
+                    red = self._bn_backward(lazy, g, g, None, do_apply=False)
+                    pw["ybn"] = (lazy.bn, red, g)
                     return
                 self._bn_backward(lazy, g, g, None)
             lazy.bn["bwd_fn"] = bwd
@@ -656,6 +699,8 @@ class Engine:
                                             res2.d() if res2 is not None else None, L.ptr(oscale), out.d(),
                                             self.st()), "isa_affine_act_res")
         if self.record:
+            pw = self._pw_out.get((raw.buf.data_ptr(), raw.c0, raw.c)) if (train and bscale is None) else None
+
             def bwd():
                 dout = self.grads.grad_of(out)
                 dsum = dout
@@ -667,6 +712,10 @@ class Engine:
                         acc = self.grads.claim(r, self)
                         L.check(self.lib.isa_axpy(dsum.d(), self.grads.grad_of(r).d(), 1.0, acc, self.st()),
                                 "isa_axpy(res)")
+                if pw is not None:                # the producing 1x1 conv's backward applies this BN on the fly
+                    red = self._bn_backward(lazy, dsum, None, None, do_apply=False)
+                    pw["ybn"] = (lazy.bn, red, dsum)
+                    return
                 self.grads.claim(raw, self)       # single consumer: overwrite
                 self._bn_backward(lazy, dsum, self.grads.grad_of(raw), bscale)
             self.tape.append(bwd)
