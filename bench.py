@@ -98,8 +98,14 @@ def main():
         model.train()
         trainer = Trainer(model, world_size=world)
 
-        def step():
+        def eager_step():
             trainer.train_step(x, sem, ins, n, selected_idx=sel)
+
+        def step():
+            if args.no_graph:
+                eager_step()
+            else:               # hipGraph replay of the same launches (trainer.py: train_step_graphed)
+                trainer.train_step_graphed(x, sem, ins, n, selected_idx=sel)
     elif workload == "train_fwd":
         model.train()
 
@@ -117,6 +123,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if workload == "train_step" and not args.no_graph:
+        log("graph setup: one eager step + one capture step (untimed, before the warmup steps)")
+        step()
+        step()
+        sync_all()
     log("workload=%s dtype=%s world=%d: warmup" % (workload, args.dtype, world))
     for _ in range(args.warmup):
         step()
@@ -143,14 +154,15 @@ def main():
         "config": {"workload": "%s %dx%d bs=%d/GPU (%s)" % (
             {"train_step": "train.py step fwd+bwd+update", "train_fwd": "ReSeg.forward(training) conv+attention head",
              "infer": "pred_list batched inference"}[workload], S, S, B, args.dtype),
-            "global_batch": world * B, "image": [S, S], "parallelism": "dp%d" % world},
+            "global_batch": world * B, "image": [S, S], "parallelism": "dp%d" % world,
+            "launch": "eager" if (args.no_graph or workload != "train_step") else "hipGraph replay"},
     }
 
     if rank == 0:
         # ---- roofline: one extra instrumented step, events on the launch stream -----------------
         E = model.engine
         E.profile = True
-        step()
+        (eager_step if workload == "train_step" else step)()      # per-launch events need the eager launch loop
         prof = E.profile_summary()
         E.profile = False
         fam = {k: v for k, v in prof.items() if v[2] > 0}

@@ -35,6 +35,7 @@ class InstanceHead:
         self.net = net
         self.E: Engine = net.E
         self.drop_rate = DROP_RATE
+        self.sample_in_training = True   # False: greedy point (argmax) also in training; parity tests inject s_t instead
         import ctypes as _C
         self._level_w = (_C.c_float * 5)(*PYRAMID_W)
         self.baseline = None            # device scalar (REINFORCE EMA baseline, attenet2.py:47,266)
@@ -239,7 +240,7 @@ class InstanceHead:
 
     # ------------------------------------------------------------------ driver (attenet2.py:357-407)
     def forward(self, x_dec: Act, feats, sem_map: torch.Tensor, ins: torch.Tensor, n_ins, training: bool,
-                selected_idx, injected_s_t=None, capture=None):
+                selected_idx, injected_s_t=None, capture=None, idx_dev=None):
         """sem_map: fp32 [n, h*w] {0,1}; ins: int64 [n,32,h,w] on device; n_ins: host ints;
         selected_idx[b]: instance order; injected_s_t: optional list of int32 device vectors (train
         sampling is injected, SURVEY §7 'RNG parity').  Returns dict of per-iteration records."""
@@ -261,9 +262,8 @@ class InstanceHead:
                 L.check(E.lib.isa_pool_target(None, None, L.ptr(sem_map), nobj, n, H, W, f, L.ptr(m), E.st()),
                         "isa_pool_target(sem)")
                 mask_all.append(m)
-        idx_host = torch.tensor([[selected_idx[b][it] for b in range(n)] for it in range(max_iter)],
-                                dtype=torch.int32).reshape(max_iter, n)
-        idx_dev = idx_host.to(E.device)
+        if idx_dev is None:          # [max_iter, n] int32 instance order; pre-staged by the graph-captured step
+            idx_dev = self.order_tensor(selected_idx, max_iter, n).to(E.device)
         skips = [feats[4], feats[3], feats[2], feats[1], feats[0]]
         iters = []
         scal = E.scratch(4)          # {ins_cost (finite part), criterion, ins_ce_loss, ins_dice_loss}
@@ -279,8 +279,14 @@ class InstanceHead:
             if injected_s_t is not None:
                 s_t = injected_s_t[it]
             else:
+                # attenet2.py:304-321 `sample`: training draws s_t ~ Multinomial(alpha), eval takes the argmax.
+                # The draw is argmax(alpha / Exp(1)) (the exponential-race form torch.multinomial itself uses
+                # for one sample); torch supplies the random numbers (graph-safe generator), the row argmax is ours.
+                src = alpha
+                if training and self.sample_in_training:
+                    src = alpha.view(n, Lp) / torch.empty(n, Lp, dtype=torch.float32, device=alpha.device).exponential_(1.0)
                 s_t = E.arena.alloc((n,), torch.int32)
-                L.check(E.lib.isa_row_argmax(L.ptr(alpha), n, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
+                L.check(E.lib.isa_row_argmax(L.ptr(src), n, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
             targets = []
             for f in FACTORS:
                 t = E.f32(n * (H // f) * (W // f))
@@ -321,6 +327,11 @@ class InstanceHead:
                 E.tape.append(bwd_losses)
             iters.append(dict(idx=idx, alpha=alpha, s_t=s_t, targets=targets, preds=preds, sums=sums))
         return dict(iters=iters, max_iter=max_iter, merge=merge, x_enc=x_enc, scal=scal)
+
+    @staticmethod
+    def order_tensor(selected_idx, max_iter, n):
+        return torch.tensor([[selected_idx[b][it] for b in range(n)] for it in range(max_iter)],
+                            dtype=torch.int32).reshape(max_iter, n)
 
     # ------------------------------------------------------------------ host-side scalar assembly
     @staticmethod

@@ -66,7 +66,9 @@ class Model(object):
         images, sem, ins, n_objects = batch
         if mode == 'training':
             self.model.train()
-            out = self.trainer.train_step(images, sem, ins, n_objects)
+            # hipGraph replay of the step (ISA_GRAPH=0: eager launch loop)
+            step = self.trainer.train_step if os.environ.get('ISA_GRAPH', '1') == '0' else self.trainer.train_step_graphed
+            out = step(images, sem, ins, n_objects)
         else:
             self.model.eval()
             with torch.no_grad():

@@ -24,8 +24,10 @@ class Trainer:
         self.acc = torch.zeros(n, dtype=torch.float32, device=st.device)      # Adadelta acc_delta
         self.sqnorm = torch.zeros(4, dtype=torch.float32, device=st.device)
         self.last = None
+        self._graphs = {}
 
-    def forward_backward(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, capture=None):
+    def forward_backward(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, capture=None,
+                         idx_dev=None):
         """Forward + backward; gradients land in model.store.grad.  Returns device scalars
         dict(sem=[ce, dice], head=[ins_cost_finite, criterion, ins_ce, ins_dice])."""
         m = self.model
@@ -45,15 +47,16 @@ class Trainer:
         sem_scal = net.sem_loss(sem_a, sem)
         head_scal = None
         if m.use_instance_seg:
-            n_ins = [int(v) for v in n_objects.reshape(-1).tolist()]
-            if selected_idx is None:
+            n_ins = n_objects if isinstance(n_objects, list) else [int(v) for v in n_objects.reshape(-1).tolist()]
+            if selected_idx is None and idx_dev is None:
                 selected_idx = []
                 for k in n_ins:
                     order = list(range(k))
                     random.shuffle(order)
                     selected_idx.append(order)
             sem_map = sem.argmax(1).reshape(x.shape[0], -1).float().contiguous()
-            rec = m.head.forward(x_dec, feats, sem_map, ins, n_ins, True, selected_idx, injected_s_t, capture)
+            rec = m.head.forward(x_dec, feats, sem_map, ins, n_ins, True, selected_idx, injected_s_t, capture,
+                                 idx_dev=idx_dev)
             m.last_record = rec
             head_scal = rec["scal"]
         E.backward()
@@ -77,3 +80,66 @@ class Trainer:
         out = self.forward_backward(x, sem, ins, n_objects, selected_idx, injected_s_t)
         self.apply_update()
         return out
+
+    # ------------------------------------------------------------------ hipGraph-captured step
+    def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None):
+        """Same step, replayed from a hipGraph: the ~2700 launches of forward+backward (+ the fused update when
+        world_size == 1) are recorded once per (shapes, iteration count) and replayed, so the GPU never waits
+        for the Python launch loop.  Inputs are copied into static device buffers; the per-step host decisions
+        (instance order) travel through a small staged index tensor; dropout masks come from torch's graph-safe
+        generator.  The first call of a configuration runs eagerly (allocations settle), the second captures.
+        With world_size > 1 the RCCL all-reduce and the update stay outside the graph."""
+        m = self.model
+        st = m.store
+        dev = st.device
+        n_ins = [int(v) for v in n_objects.reshape(-1).tolist()]
+        from .instance_head import MAX_ITER
+        max_iter = min(MAX_ITER, min(n_ins)) if m.use_instance_seg else 0
+        if m.use_instance_seg and selected_idx is None:
+            selected_idx = []
+            for k in n_ins:
+                order = list(range(k))
+                random.shuffle(order)
+                selected_idx.append(order)
+        key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
+               m.engine.dtype)
+        slot = self._graphs.get(key)
+        if slot is None:                         # first sight: eager step, remember the configuration
+            self._graphs[key] = dict(state="warm")
+            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx)
+        if slot["state"] == "warm":
+            slot["x"] = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
+            slot["sem"] = torch.empty(tuple(sem.shape), dtype=sem.dtype, device=dev)
+            slot["ins"] = torch.empty(tuple(ins.shape), dtype=ins.dtype, device=dev)
+            slot["idx"] = torch.zeros((max(max_iter, 1), x.shape[0]), dtype=torch.int32, device=dev)
+            slot["idx_pin"] = torch.zeros((max(max_iter, 1), x.shape[0]), dtype=torch.int32).pin_memory()
+            self._stage(slot, x, sem, ins, selected_idx, max_iter)
+            before = dict(st.int_buffers)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"])
+                if self.world == 1:
+                    self.apply_update()
+            # capture only records: undo its host-side counters, replay() below performs the step
+            slot["bumps"] = {k: v - before[k] for k, v in st.int_buffers.items() if v != before[k]}
+            st.int_buffers.update(before)
+            slot.update(state="ready", graph=g, out=out)
+        else:
+            self._stage(slot, x, sem, ins, selected_idx, max_iter)
+        slot["graph"].replay()
+        for k, v in slot["bumps"].items():
+            st.int_buffers[k] += v
+        if self.world > 1:
+            self.apply_update()
+        m.mark_weights_dirty()
+        self.last = slot["out"]
+        return self.last
+
+    def _stage(self, slot, x, sem, ins, selected_idx, max_iter):
+        slot["x"].copy_(x, non_blocking=True)
+        slot["sem"].copy_(sem, non_blocking=True)
+        slot["ins"].copy_(ins, non_blocking=True)
+        if max_iter > 0:
+            n = slot["x"].shape[0]
+            slot["idx_pin"].copy_(self.model.head.order_tensor(selected_idx, max_iter, n))
+            slot["idx"].copy_(slot["idx_pin"], non_blocking=True)
