@@ -80,6 +80,16 @@ __device__ __forceinline__ void stage_tile(const Dw2Params& p, const ProRegs& r,
     }
 }
 
+// acc[j] += x[j] * w[j] for 8 channels as four v_pk_fma_f32 (packed fp32: two FMAs per lane per issue)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma8(const float (&x)[8], const float (&w)[8], float (&acc)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 r = __builtin_elementwise_fma(f32x2{x[j], x[j + 1]}, f32x2{w[j], w[j + 1]}, f32x2{acc[j], acc[j + 1]});
+        acc[j] = r[0]; acc[j + 1] = r[1];
+    }
+}
+
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -126,8 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int o = 0; o < 4; ++o)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(in[o + k][j], wr[k][j], acc[o][j]);
+                fma8(in[o + k], wr[k], acc[o]);
     }
     const int oy = ty * TH + row;
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -220,8 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[dy * 3 + k][j] = fmaf(in[o + k][j], d[o][j], acc[dy * 3 + k][j]);
+                    fma8(in[o + k], d[o], acc[dy * 3 + k]);
             __builtin_amdgcn_sched_barrier(0);       // keep one row of LDS reads live at a time (register budget)
         }
     }
@@ -341,23 +349,33 @@ __global__ void collapse8_kernel(float* red, int n2c) {
 
 // XMODE 0: x is a plain tensor; 1: x = relu6(BN(x_raw)) and its backward sums are produced;
 //       2: x has a runtime prologue, sums produced when p.xred != null
-template <typename T, int YACT, int XMODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_bn_bwd_kernel(FusedParams p) {
+// DB (bf16): 512 threads, two LDS tile buffers.  Waves 4-7 only stage the NEXT tile (all of its 16-byte loads in
+// flight at once, BN-backward / prologue arithmetic, LDS stores) while waves 0-3 run the two stencils on the
+// current one; one __syncthreads per tile swaps the buffers.  The single-buffer form (f32 storage: the tiles do
+// not fit twice) runs the same phases back to back in 256 threads.  Measured on the 256x256x64 level: PMC showed
+// the single-buffer kernel waiting on memory for most of each tile (2 waves/SIMD, phases serialised).
+template <typename T, int YACT, int XMODE, bool DB>
+__global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_bn_bwd_kernel(FusedParams p) {
     constexpr int PSD = dd_stride<T>::v;
     constexpr int XACT = XMODE == 1 ? ISA_ACT_RELU6 : (XMODE == 0 ? ISA_ACT_NONE : ACT_RT);
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int NTHR = DB ? 512 : 256;
+    constexpr int XT_FLOATS = HALO * PS, DT_ELEMS = HALO * PSD;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xt = sm;                                              // [HALO][PS]  pro(x), fp32
-    T* dt = reinterpret_cast<T*>(sm + HALO * PS);                // [HALO][PSD] dy, storage type
-    float* wts = reinterpret_cast<float*>(dt + HALO * PSD);      // [9][CB] flipped taps
-    float* cst = wts + 9 * CB;                                   // [10][CB] per-channel constants
-    float* red = cst + 10 * CB;                                  // [10*CB]
+    float* xt_base = sm;                                                     // [NBUF][HALO][PS]  pro(x), fp32
+    T* dt_base = reinterpret_cast<T*>(sm + NBUF * XT_FLOATS);                // [NBUF][HALO][PSD] dy, storage type
+    float* wts = reinterpret_cast<float*>(dt_base + NBUF * DT_ELEMS);        // [9][CB] flipped taps
+    float* cst = wts + 9 * CB;                                               // [10][CB] per-channel constants
+    float* red = cst + 10 * CB;                                              // [10*CB]
     const int tid = threadIdx.x;
+    const int ltid = tid & 255;                                              // index inside the role group
+    const bool loader = DB && tid >= 256;
     const int c_base = blockIdx.y * CB;
-    const int cg = tid & 3, g4 = tid >> 2, row = g4 >> 3, x0 = (g4 & 7) * 4;
+    const int cg = ltid & 3, g4 = ltid >> 2, row = g4 >> 3, x0 = (g4 & 7) * 4;
     const int c0 = c_base + cg * 8;
     const bool cok = c0 < p.c;
     const T* wp = reinterpret_cast<const T*>(p.w);
-    for (int i = tid; i < 9 * CB; i += 256) {
+    for (int i = tid; i < 9 * CB; i += NTHR) {
         const int tp = i / CB, cc = i - tp * CB;
         wts[i] = (c_base + cc < p.c) ? st<T>::ld(wp + (long)tp * p.wld + c_base + cc) : 0.f;
     }
@@ -373,27 +391,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (p.ydbeta) atomicAdd(p.ydbeta + c, p.yred[c]);
         }
     }
-    float acc[9][8], s0[8], s1[8];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    for (int i = tid; i < 11 * CB; i += NTHR) red[i] = 0.f;     // rows 0-8: dW taps, 9-10: BN(x) sums
     const T* gin = reinterpret_cast<const T*>(p.g);
     const T* yin = reinterpret_cast<const T*>(p.y);
     const T* xin = reinterpret_cast<const T*>(p.x);
     T* dxo = reinterpret_cast<T*>(p.dx);
     constexpr int NIT = (HALO * 4 + 255) / 256;
-    constexpr int NB = 3;
+    constexpr int NB = DB ? NIT : 3;                 // loader waves own their registers: a whole tile in flight
     static_assert(NIT % NB == 0, "staging chunks");
     const bool want_xred = XMODE == 1 || (XMODE == 2 && p.xred != nullptr);
 
-    for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    auto stage = [&](long t, float* xt, T* dt) {
         const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
         const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
-        __syncthreads();                                         // constants visible / previous tile fully consumed
-        {   // ---- stage dy = BN-backward(g, y) with halo, NB vectors per lane at a time
+        {   // ---- dy = BN-backward(g, y) with halo
             float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
             ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
             ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 raw8<T> gv[NB], yv[NB]; bool ok[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int pix = (ltid + (it0 + u) * 256) >> 2;
                     const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
                     const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
                     ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int pix = (ltid + (it0 + u) * 256) >> 2;
                     if (pix >= HALO) continue;
                     float o[8];
 #pragma unroll
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        {   // ---- stage pro(x) with halo (fp32)
+        {   // ---- pro(x) with halo (fp32)
             float sc[8], sh[8];
             ld8(cst + 6 * CB + cg * 8, sc); ld8(cst + 7 * CB + cg * 8, sh);
 #pragma unroll
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 raw8<T> xv[NB]; bool ok[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int pix = (ltid + (it0 + u) * 256) >> 2;
                     const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
                     const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
                     ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int pix = (tid + (it0 + u) * 256) >> 2;
+                    const int pix = (ltid + (it0 + u) * 256) >> 2;
                     if (pix >= HALO) continue;
                     float o[8];
 #pragma unroll
@@ -464,8 +475,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
+    };
+
+    auto compute = [&](long t, const float* xt, const T* dt, float (&acc)[9][8], float (&s0)[8], float (&s1)[8]) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
         const int oy = ty * TH + row;
+        // operands of the epilogue (old dx for accumulate, raw x for the BN(x) sums) are requested before the
+        // stencil so their latency hides behind it: a compute wave has no sibling wave to switch to
+        raw8<T> xc[4], oc[4];
+        if (oy < p.h && cok) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int ox = tx * TW + x0 + o;
+                if (ox >= p.w_) continue;
+                const long po = ((long)b * p.h + oy) * p.w_ + ox;
+                if (want_xred) xc[o].load(xin + po * p.ldx + c0);
+                if (p.accumulate) oc[o].load(dxo + po * p.lddx + c0);
+            }
+        }
         {   // ---- data gradient: dx tile = flipped taps over dy (halo), then BN(x)-backward sums
             float a[4][8];
 #pragma unroll
@@ -483,8 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) a[o][j] = fmaf(in[o + k][j], wr[k][j], a[o][j]);
+                        fma8(in[o + k], wr[k], a[o]);
             }
             if (oy < p.h && cok) {
                 float xs[8], xh[8], xm[8], xi[8];
@@ -499,14 +526,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const long po = ((long)b * p.h + oy) * p.w_ + ox;
                     T* dst = dxo + po * p.lddx + c0;
                     if (p.accumulate) {
-                        float old[8]; load8<T>(dst, old);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[o][j] += old[j];
+                        for (int j = 0; j < 8; ++j) a[o][j] += oc[o].get(j);
                     }
                     store8<T>(dst, a[o]);
                     if (want_xred) {
                         // the unfused reduce reads the stored (rounded) gradient: round the same way
-                        float xr[8]; load8<T>(xin + po * p.ldx + c0, xr);
+                        float xr[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xr[j] = xc[o].get(j);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float gq = (float)(T)a[o][j];
@@ -532,60 +560,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[dy * 3 + k][j] = fmaf(in[o + k][j], d[o][j], acc[dy * 3 + k][j]);
+                        fma8(in[o + k], d[o], acc[dy * 3 + k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < 10 * CB; i += 256) red[i] = 0.f;
-    __syncthreads();
+    };
+
+    // The accumulators exist only on the compute side of the role split, so the register allocator sees
+    // max(loader set, compute set) instead of their sum.  Both sides execute the same number of barriers.
+    __syncthreads();                                             // constants + zeroed `red` visible
+    if (loader) {
+        long t = blockIdx.x;
+        int buf = 0;
+        if (t < p.ntiles) stage(t, xt_base, dt_base);
+        __syncthreads();                                         // first tile staged
+        for (; t < p.ntiles; t += gridDim.x) {
+            const long tn = t + gridDim.x;
+            if (tn < p.ntiles) stage(tn, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        float acc[9][8], s0[8], s1[8];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = acc[tp][j];
+            for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
 #pragma unroll
-            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+        for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+        if constexpr (DB) {
+            long t = blockIdx.x;
+            int buf = 0;
+            __syncthreads();                                     // first tile staged
+            for (; t < p.ntiles; t += gridDim.x) {
+                compute(t, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+                stage(t, xt_base, dt_base);
+                __syncthreads();
+                compute(t, xt_base, dt_base, acc, s0, s1);
+                __syncthreads();                                 // tile fully consumed before it is restaged
+            }
+        }
+        // fold this lane's sums: 16 lanes share a channel group, then 4 LDS atomics per wave and value
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = acc[tp][j];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+                if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+            }
+        }
+        if (want_xred) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v0 = s0[j], v1 = s1[j];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
+                if ((tid & 63) < 4) { atomicAdd(&red[9 * CB + cg * 8 + j], v0); atomicAdd(&red[10 * CB + cg * 8 + j], v1); }
+            }
         }
     }
     __syncthreads();
     float* slab = p.ws + ((long)blockIdx.x * gridDim.y + blockIdx.y) * 10 * CB;
-    for (int i = tid; i < 10 * CB; i += 256) slab[i] = red[i];
-    if (want_xred) {
-        __syncthreads();
-        if (tid < 2 * CB) red[tid] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v0 = s0[j], v1 = s1[j];
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
-            if ((tid & 63) < 4) { atomicAdd(&red[cg * 8 + j], v0); atomicAdd(&red[CB + cg * 8 + j], v1); }
-        }
-        __syncthreads();
-        if (tid < 2 * CB) {
-            const int cc = tid & (CB - 1), which = tid / CB;
-            if (c_base + cc < p.c && red[tid] != 0.f) {
-                float* rep = p.xred + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
-                atomicAdd(rep + which * p.c + c_base + cc, red[tid]);
-            }
+    for (int i = tid; i < 10 * CB; i += NTHR) slab[i] = i < 9 * CB ? red[i] : 0.f;       // row 9 = conv bias slot (none here)
+    if (want_xred && tid < 2 * CB) {
+        const int cc = tid & (CB - 1), which = tid / CB;
+        const float v = red[9 * CB + tid];
+        if (c_base + cc < p.c && v != 0.f) {
+            float* rep = p.xred + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
+            atomicAdd(rep + which * p.c + c_base + cc, v);
         }
     }
 }
 
 template <typename T, int YACT, int XMODE>
 int launch_fused_inst(FusedParams& p, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)HALO * PS * 4 + (size_t)HALO * dd_stride<T>::v * sizeof(T) + (9 + 10 + 10) * CB * 4;
+    constexpr bool DB = sizeof(T) == 2;                          // two tile buffers fit in 160 KB only for bf16
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr size_t lds = NBUF * ((size_t)HALO * PS * 4 + (size_t)HALO * dd_stride<T>::v * sizeof(T)) + (9 + 10 + 11) * CB * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bn_bwd_kernel<T, YACT, XMODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bn_bwd_kernel<T, YACT, XMODE, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISA_ELAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((dw_bn_bwd_kernel<T, YACT, XMODE>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((dw_bn_bwd_kernel<T, YACT, XMODE, DB>), grid, dim3(DB ? 512 : 256), lds, s, p);
     return ISA_OK;
 }
 
@@ -594,7 +659,7 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
     const int ncb = (p.c + CB - 1) / CB;
-    const int per_cu = sizeof(T) == 2 ? 2 : 1;                   // LDS: 79 KB (bf16) / 100 KB (f32) per workgroup
+    const int per_cu = 1;                                        // LDS: 156 KB (bf16, double-buffered) / 100 KB (f32)
     long gx = (256L * per_cu) / ncb;
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
