@@ -118,7 +118,7 @@ int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tenso
 
 /* Backward constants of one train-mode BatchNorm2d layer (what torch autograd keeps for
  * native_batch_norm_backward): scale/shift/mean/invstd from isa_bn_finalize, `red` = the
- * [ISA_STAT_REPLICAS][2C] sums written by isa_bn_bwd_reduce (folded in place by the consumer),
+ * [ISA_STAT_REPLICAS][2C] sums written by isa_bn_bwd_reduce (the consumer adds the replicas),
  * `out_red` = where a fused producer writes those sums, dgamma/dbeta accumulate (may be NULL).     */
 typedef struct isa_bn_bwd {
     const float* scale; const float* shift; const float* mean; const float* invstd;

@@ -28,15 +28,6 @@ struct PwParams {
     int accumulate; float* ws;
 };
 
-__global__ void collapse_red_kernel(float* red, int n2c) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2c; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < ISA_STAT_R; ++r) s += red[r * n2c + i];
-        red[i] = s;
-    }
-}
-
 // XMODE 0: plain x; 1: x = relu6(scale*x+shift) with BN(x) sums produced; 2: runtime prologue, sums if p.xred
 template <int TN, int TK, int YACT, int XMODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_bn_bwd_kernel(PwParams p) {
@@ -65,8 +56,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < 64) {
         const int cn = min(tid, p.N - 1), ck = min(tid, p.K - 1);
         cst[0 * 64 + tid] = p.ysc[cn]; cst[1 * 64 + tid] = p.ysh[cn]; cst[2 * 64 + tid] = p.ymu[cn];
-        cst[3 * 64 + tid] = p.yis[cn] * (p.yred[p.N + cn] * p.ycnt_inv);     // invstd * mean(g' * yhat)
-        cst[4 * 64 + tid] = p.yred[cn] * p.ycnt_inv;                          // mean(g')
+        float r0 = 0.f, r1 = 0.f;                                             // fold the ISA_STAT_R replicas
+#pragma unroll
+        for (int r = 0; r < ISA_STAT_R; ++r) { r0 += p.yred[r * 2 * p.N + cn]; r1 += p.yred[r * 2 * p.N + p.N + cn]; }
+        cst[3 * 64 + tid] = p.yis[cn] * (r1 * p.ycnt_inv);                    // invstd * mean(g' * yhat)
+        cst[4 * 64 + tid] = r0 * p.ycnt_inv;                                  // mean(g')
+        if (blockIdx.x == 0 && tid < p.N) {                                   // BN(y) parameter gradients
+            if (p.ydgamma) atomicAdd(p.ydgamma + tid, r1);
+            if (p.ydbeta) atomicAdd(p.ydbeta + tid, r0);
+        }
         cst[5 * 64 + tid] = (XMODE && p.xsc) ? p.xsc[ck] : 1.f; cst[6 * 64 + tid] = (XMODE && p.xsh) ? p.xsh[ck] : 0.f;
         cst[7 * 64 + tid] = (XMODE && p.xmu) ? p.xmu[ck] : 0.f; cst[8 * 64 + tid] = (XMODE && p.xis) ? p.xis[ck] : 1.f;
     }
@@ -76,10 +74,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
     };
-    if (blockIdx.x == 0 && tid < p.N) {                           // BN(y) parameter gradients
-        if (p.ydgamma) atomicAdd(p.ydgamma + tid, p.yred[p.N + tid]);
-        if (p.ydbeta) atomicAdd(p.ydbeta + tid, p.yred[tid]);
-    }
     // ---- W fragments for the data gradient: B[n = 16 s + 8 hh + jj][k = 32 j + r], rounded to bf16 once
     bf16x8 wb[NS][TK];
 #pragma unroll
@@ -337,7 +331,6 @@ extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y,
     int xmode = 0;
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(collapse_red_kernel, dim3(cdiv(2 * N, 256)), dim3(256), 0, s, ybn->red, 2 * N);
     const int tn = (N + 31) / 32, tk = (K + 31) / 32;
     if (tn == 1 && tk == 1) return launch_tile<1, 1>(p, xmode, ws_floats, s);
     if (tn == 1 && tk == 2) return launch_tile<1, 2>(p, xmode, ws_floats, s);

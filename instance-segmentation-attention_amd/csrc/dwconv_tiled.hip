@@ -338,17 +338,6 @@ template <> struct raw8<float> {
 template <typename T> struct dd_stride { static constexpr int v = 36; };       // floats: 144 B / pixel
 template <> struct dd_stride<bf16_t> { static constexpr int v = 40; };         // 80 B / pixel: 4 x-groups tile 256 B
 
-__global__ void collapse8_kernel(float* red, int n2c) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2c; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < ISA_STAT_R; ++r) s += red[r * n2c + i];
-        red[i] = s;
-    }
-}
-
-// XMODE 0: x is a plain tensor; 1: x = relu6(BN(x_raw)) and its backward sums are produced;
-//       2: x has a runtime prologue, sums produced when p.xred != null
 // DB (bf16): 512 threads, two LDS tile buffers.  Waves 4-7 only stage the NEXT tile (all of its 16-byte loads in
 // flight at once, BN-backward / prologue arithmetic, LDS stores) while waves 0-3 run the two stencils on the
 // current one; one __syncthreads per tile swaps the buffers.  The single-buffer form (f32 storage: the tiles do
@@ -383,12 +372,15 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         const int c = min(c_base + tid, p.c - 1);
         cst[0 * CB + tid] = p.ysc[c]; cst[1 * CB + tid] = p.ysh[c];
         cst[2 * CB + tid] = p.ymu[c]; cst[3 * CB + tid] = p.yis[c];
-        cst[4 * CB + tid] = p.yred[c] * p.ycnt_inv; cst[5 * CB + tid] = p.yred[p.c + c] * p.ycnt_inv;
+        float r0 = 0.f, r1 = 0.f;                                // fold the ISA_STAT_R replicas of BN(y)'s backward sums
+#pragma unroll
+        for (int r = 0; r < ISA_STAT_R; ++r) { r0 += p.yred[r * 2 * p.c + c]; r1 += p.yred[r * 2 * p.c + p.c + c]; }
+        cst[4 * CB + tid] = r0 * p.ycnt_inv; cst[5 * CB + tid] = r1 * p.ycnt_inv;
         cst[6 * CB + tid] = (XMODE && p.xsc) ? p.xsc[c] : 1.f; cst[7 * CB + tid] = (XMODE && p.xsh) ? p.xsh[c] : 0.f;
         cst[8 * CB + tid] = (XMODE && p.xmu) ? p.xmu[c] : 0.f; cst[9 * CB + tid] = (XMODE && p.xis) ? p.xis[c] : 1.f;
         if (blockIdx.x == 0 && c_base + tid < p.c) {             // BN(y) parameter gradients: dbeta = sum g', dgamma = sum g'*yhat
-            if (p.ydgamma) atomicAdd(p.ydgamma + c, p.yred[p.c + c]);
-            if (p.ydbeta) atomicAdd(p.ydbeta + c, p.yred[c]);
+            if (p.ydgamma) atomicAdd(p.ydgamma + c, r1);
+            if (p.ydbeta) atomicAdd(p.ydbeta + c, r0);
         }
     }
     for (int i = tid; i < 11 * CB; i += NTHR) red[i] = 0.f;     // rows 0-8: dW taps, 9-10: BN(x) sums
@@ -667,7 +659,6 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     if (ws_cap < 1) return ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
     dim3 grid((unsigned)gx, ncb);
-    hipLaunchKernelGGL(collapse8_kernel, dim3(cdiv(2 * p.c, 256)), dim3(256), 0, s, const_cast<float*>(p.yred), 2 * p.c);
     int rc;
     const bool y6 = p.yact == ISA_ACT_RELU6;
     if (xmode == 0) rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 0>(p, grid, s) : launch_fused_inst<T, ACT_RT, 0>(p, grid, s);

@@ -109,31 +109,33 @@ static inline Walk mkwalk(int c, long pixels) {
     if (w.sh > 8) w.sh = 8;
     w.pixels = pixels; return w;
 }
-static inline int walk_grid(const Walk& w) { return grid_cap(cdiv(w.pixels, 256 >> w.sh)); }
-
-// red[0][i] = sum_r red[r][i]: collapse the statistic replicas once, so the streaming pass reads 2 floats
-// per channel instead of 2*ISA_STAT_R
-__global__ void collapse_replicas_kernel(float* red, int n2c) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2c; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < ISA_STAT_R; ++r) s += red[r * n2c + i];
-        red[i] = s;
-    }
-}
+// `iters` = pixel iterations a workgroup should own at least: kernels with a per-workgroup prologue/epilogue of
+// O(C) global accesses (the BN-backward passes) must not be launched as thousands of one-iteration workgroups on
+// the wide, low-resolution levels (4096 px x 512 ch: the epilogue atomics outnumbered the data 16:1)
+static inline int walk_grid(const Walk& w, int iters = 1) { return grid_cap(cdiv(w.pixels, (long)(256 >> w.sh) * iters)); }
 
 // z = scale*y+shift ; dz = dt * bscale * act'(z)
 template <typename T, bool APPLY, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
-    extern __shared__ float red[];              // reduce pass: [2*C]
+    extern __shared__ float red[];              // [2*C]: reduce pass partial sums / apply pass folded sums
     const int C = p.y.c;
     if (!APPLY) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
-    } else if (blockIdx.x == 0 && p.train) {
-        for (int i = threadIdx.x; i < C; i += 256) {        // p.red: replicas already collapsed into [0]
-            if (p.dgamma) atomicAdd(p.dgamma + i, p.red[C + i]);
-            if (p.dbeta) atomicAdd(p.dbeta + i, p.red[i]);
+    } else if (p.train) {
+        // fold the ISA_STAT_R replicas of the reduce pass once per workgroup (2C x 8 loads spread over 256 lanes)
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < ISA_STAT_R; ++r) s += p.red[r * 2 * C + i];
+            red[i] = s;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            for (int i = threadIdx.x; i < C; i += 256) {
+                if (p.dgamma) atomicAdd(p.dgamma + i, red[C + i]);
+                if (p.dbeta) atomicAdd(p.dbeta + i, red[i]);
+            }
         }
     }
     const int ppb = 256 >> wk.sh;
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
             sh[j] = p.shift ? p.shift[c] : 0.f;
             mu[j] = p.mean ? p.mean[c] : 0.f;
             is[j] = p.invstd ? p.invstd[c] : 1.f;
-            k0[j] = (APPLY && p.train) ? p.red[c] * p.inv_count : 0.f;
-            k1[j] = (APPLY && p.train) ? p.red[C + c] * p.inv_count : 0.f;
+            k0[j] = (APPLY && p.train) ? red[c] * p.inv_count : 0.f;
+            k1[j] = (APPLY && p.train) ? red[C + c] * p.inv_count : 0.f;
             s0[j] = 0.f; s1[j] = 0.f;
         }
         const long step = (long)gridDim.x * ppb;
@@ -492,9 +494,9 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
     if (p.pixels >= (1L << 32)) return ISA_EINVAL;
     const Walk wk = mkwalk(y->c, p.pixels);
-    int grid = walk_grid(wk);
+    int grid = walk_grid(wk, 16);
     if (!apply && grid > 1024) grid = 1024;     // every block ends with 2C global atomics (8 replicas)
-    const size_t lds = apply ? 0 : 2 * (size_t)y->c * 4;
+    const size_t lds = 2 * (size_t)y->c * 4;
 #define BN_BWD_LAUNCH(AP, ACTV) \
     DISPATCH_T(y->dtype, \
         hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk), \
@@ -528,9 +530,6 @@ extern "C" int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const
                                 const float* red, float count, int32_t train,
                                 const isa_tensor* dy, float* dgamma, float* dbeta, void* stream) {
     if (train && !red) return ISA_EINVAL;
-    if (train)      // red is [ISA_STAT_R][2C]; fold it into replica 0 (the caller's buffer is scratch)
-        hipLaunchKernelGGL(collapse_replicas_kernel, dim3(cdiv(2 * y->c, 256)), dim3(256), 0, as_stream(stream),
-                           const_cast<float*>(red), 2 * y->c);
     BnBwdParams p{};
     p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.bscale = bscale;
     p.gamma = gamma; p.red = red; p.inv_count = count > 0 ? 1.f / count : 0.f;
