@@ -123,25 +123,29 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
     } else if (p.train) {
-        // fold the ISA_STAT_R replicas of the reduce pass once per workgroup (2C x 8 loads spread over 256 lanes)
-        for (int i = threadIdx.x; i < 2 * C; i += 256) {
-            float s = 0.f;
+        // fold the ISA_STAT_R replicas of the reduce pass once per workgroup, for the channels this workgroup
+        // owns (blockIdx.y = channel chunk on wide tensors)
+        const int cw = 8 << wk.sh;                                // channels per chunk
+        for (int cb = blockIdx.y * cw; cb < C; cb += gridDim.y * cw) {
+            for (int i = threadIdx.x; i < 2 * cw; i += 256) {
+                const int which = i / cw, c = cb + (i - which * cw);
+                if (c >= C) continue;
+                float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < ISA_STAT_R; ++r) s += p.red[r * 2 * C + i];
-            red[i] = s;
-        }
-        __syncthreads();
-        if (blockIdx.x == 0) {
-            for (int i = threadIdx.x; i < C; i += 256) {
-                if (p.dgamma) atomicAdd(p.dgamma + i, red[C + i]);
-                if (p.dbeta) atomicAdd(p.dbeta + i, red[i]);
+                for (int r = 0; r < ISA_STAT_R; ++r) s += p.red[r * 2 * C + which * C + c];
+                red[which * C + c] = s;
+                if (blockIdx.x == 0) {
+                    if (which == 1 && p.dgamma) atomicAdd(p.dgamma + c, s);
+                    if (which == 0 && p.dbeta) atomicAdd(p.dbeta + c, s);
+                }
             }
         }
+        __syncthreads();
     }
     const int ppb = 256 >> wk.sh;
     const int psub = threadIdx.x >> wk.sh;
     const unsigned hw = (unsigned)p.y.h * (unsigned)p.y.w;
-    for (int cgi = threadIdx.x & ((1 << wk.sh) - 1); cgi < wk.cg; cgi += (1 << wk.sh)) {
+    for (int cgi = (blockIdx.y << wk.sh) + (threadIdx.x & ((1 << wk.sh) - 1)); cgi < wk.cg; cgi += (gridDim.y << wk.sh)) {
         const int c0 = cgi * 8;
         const int nv = min(8, C - c0);
         float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], s0[8], s1[8];
@@ -493,14 +497,30 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     if (apply) { if (!tensor_ok(dy, 8) || !same_shape(dy, y)) return ISA_EINVAL; p.dy = mkview(dy); }
     p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
     if (p.pixels >= (1L << 32)) return ISA_EINVAL;
-    const Walk wk = mkwalk(y->c, p.pixels);
-    int grid = walk_grid(wk, 16);
-    if (!apply && grid > 1024) grid = 1024;     // every block ends with 2C global atomics (8 replicas)
+    // wide tensors (> 128 channels): blockIdx.y owns a 32-channel chunk, so a workgroup's O(C) prologue /
+    // epilogue (replica fold, per-channel atomics) covers 32 channels instead of C, and the pixel dimension can
+    // be split across enough workgroups to fill the chip (16x16x16 px x 1024 ch used to run as 128 workgroups
+    // of 16 serial iterations each)
+    Walk wk = mkwalk(y->c, p.pixels);
+    int gy = 1, grid;
+    if (wk.cg > 16) {
+        // 32-channel chunks x 64 pixel rows per trip; the reduce pass keeps <= 128 pixel splits so that its
+        // splits x 2C epilogue atomics stay small next to the data, the apply pass splits further
+        wk.sh = 2; gy = (wk.cg + 3) / 4;
+        const long trips = cdiv(p.pixels, 64);
+        grid = (int)(apply ? (trips + 1) / 2 : (trips + 3) / 4);
+        const int cap = apply ? 512 : 128;
+        if (grid > cap) grid = cap;
+        if (grid < 1) grid = 1;
+    } else {
+        grid = walk_grid(wk, 16);
+        if (!apply && grid > 1024) grid = 1024;     // every block ends with 2C global atomics (8 replicas)
+    }
     const size_t lds = 2 * (size_t)y->c * 4;
 #define BN_BWD_LAUNCH(AP, ACTV) \
     DISPATCH_T(y->dtype, \
-        hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk), \
-        hipLaunchKernelGGL((bn_bwd_kernel<float, AP, ACTV>), dim3(grid), dim3(256), lds, as_stream(stream), p, wk))
+        hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid, gy), dim3(256), lds, as_stream(stream), p, wk), \
+        hipLaunchKernelGGL((bn_bwd_kernel<float, AP, ACTV>), dim3(grid, gy), dim3(256), lds, as_stream(stream), p, wk))
     if (apply) {
         if (p.act == ISA_ACT_RELU6) BN_BWD_LAUNCH(true, ISA_ACT_RELU6);
         else if (p.act == ISA_ACT_NONE) BN_BWD_LAUNCH(true, ISA_ACT_NONE);
