@@ -110,16 +110,19 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 }
 
 // compile-time activation: ACT = ISA_ACT_RELU6 / ISA_ACT_NONE are specialised (branch-free inner loops),
-// ACT = -1 takes the runtime switch.  Hot kernels are instantiated for {RELU6, runtime}.
+// ACT = -1 takes the runtime switch (its tanhf branch alone triples the prologue code).  Hot kernels are
+// instantiated for {RELU6, LEAKY where the prediction heads use it, runtime}.
 constexpr int ACT_RT = -1;
 template <int ACT> __device__ __forceinline__ float act_t(float z, int rt) {
     if constexpr (ACT == ISA_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
     else if constexpr (ACT == ISA_ACT_NONE) return z;
+    else if constexpr (ACT == ISA_ACT_LEAKY) return z > 0.f ? z : 0.01f * z;
     else return act_apply(z, rt);
 }
 template <int ACT> __device__ __forceinline__ float act_grad_t(float z, int rt) {
     if constexpr (ACT == ISA_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
     else if constexpr (ACT == ISA_ACT_NONE) return 1.f;
+    else if constexpr (ACT == ISA_ACT_LEAKY) return z > 0.f ? 1.f : 0.01f;
     else return act_grad(z, rt);
 }
 

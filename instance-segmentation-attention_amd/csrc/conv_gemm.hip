@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N_BLK = 32 * NT;
     constexpr bool HAS_PRO = PRO != 0;
-    constexpr int ACT = PRO == 1 ? ISA_ACT_RELU6 : ACT_RT;
+    constexpr int ACT = PRO == 1 ? ISA_ACT_RELU6 : (PRO == 3 ? ISA_ACT_LEAKY : ACT_RT);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int n0 = blockIdx.y * N_BLK;
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 template <typename T, int NT, int IN_MODE, int OUT_MODE>
 int launch2(const GemmParams& p, bool has_pro, dim3 grid, size_t lds, hipStream_t s) {
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1>), grid, dim3(256), lds, s, p);
+    else if (has_pro && p.pro.act == ISA_ACT_LEAKY && IN_MODE == ISA_IN_3X3) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 3>), grid, dim3(256), lds, s, p);
     else if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 2>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 0>), grid, dim3(256), lds, s, p);
     return launch_status();

@@ -469,6 +469,7 @@ int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
     const int gx = (int)(want < cap ? want : cap);
     dim3 grid(gx, gy, p.taps);
     if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
+    else if (p.pro.act == ISA_ACT_LEAKY && TN == 1 && TK == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_LEAKY>), grid, dim3(256), lds, s, p);
     else if (p.pro.act == ISA_ACT_NONE) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ACT_RT>), grid, dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;

@@ -82,7 +82,7 @@ class Trainer:
         return out
 
     # ------------------------------------------------------------------ hipGraph-captured step
-    def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None):
+    def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None):
         """Same step, replayed from a hipGraph: the ~2700 launches of forward+backward (+ the fused update when
         world_size == 1) are recorded once per (shapes, iteration count) and replayed, so the GPU never waits
         for the Python launch loop.  Inputs are copied into static device buffers; the per-step host decisions
@@ -102,22 +102,24 @@ class Trainer:
                 random.shuffle(order)
                 selected_idx.append(order)
         key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
-               m.engine.dtype)
+               m.engine.dtype, injected_s_t is not None)
         slot = self._graphs.get(key)
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")
-            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx)
+            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
         if slot["state"] == "warm":
             slot["x"] = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
             slot["sem"] = torch.empty(tuple(sem.shape), dtype=sem.dtype, device=dev)
             slot["ins"] = torch.empty(tuple(ins.shape), dtype=ins.dtype, device=dev)
             slot["idx"] = torch.zeros((max(max_iter, 1), x.shape[0]), dtype=torch.int32, device=dev)
             slot["idx_pin"] = torch.zeros((max(max_iter, 1), x.shape[0]), dtype=torch.int32).pin_memory()
-            self._stage(slot, x, sem, ins, selected_idx, max_iter)
+            slot["inj"] = None if injected_s_t is None else [torch.zeros_like(t) for t in injected_s_t[:max_iter]]
+            self._stage(slot, x, sem, ins, selected_idx, max_iter, injected_s_t)
             before = dict(st.int_buffers)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"])
+                out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
+                                            injected_s_t=slot["inj"])
                 if self.world == 1:
                     self.apply_update()
             # capture only records: undo its host-side counters, replay() below performs the step
@@ -125,7 +127,7 @@ class Trainer:
             st.int_buffers.update(before)
             slot.update(state="ready", graph=g, out=out)
         else:
-            self._stage(slot, x, sem, ins, selected_idx, max_iter)
+            self._stage(slot, x, sem, ins, selected_idx, max_iter, injected_s_t)
         slot["graph"].replay()
         for k, v in slot["bumps"].items():
             st.int_buffers[k] += v
@@ -135,7 +137,10 @@ class Trainer:
         self.last = slot["out"]
         return self.last
 
-    def _stage(self, slot, x, sem, ins, selected_idx, max_iter):
+    def _stage(self, slot, x, sem, ins, selected_idx, max_iter, injected_s_t=None):
+        if slot.get("inj") is not None:          # parity runs: glimpse points fixed from outside
+            for dst, src in zip(slot["inj"], injected_s_t):
+                dst.copy_(src, non_blocking=True)
         slot["x"].copy_(x, non_blocking=True)
         slot["sem"].copy_(sem, non_blocking=True)
         slot["ins"].copy_(ins, non_blocking=True)

@@ -155,13 +155,17 @@ def test_graph_replayed_step_matches_eager_step(dtype):
     m.head.drop_rate = 0.0
     m.head.sample_in_training = False                                   # no RNG: eager and replay see the same points
     tr = Trainer(m)
-    tr.train_step_graphed(x, sem, ins, n, selected_idx=order_a)        # first sight of the shapes: eager
+    # glimpse points are injected: an argmax near-tie flipping between two runs changes the whole decoder gradient,
+    # which would measure the network's sensitivity, not the replay
+    inj = [torch.tensor([64 * 20 + 9, 64 * 41 + 30], dtype=torch.int32, device="cuda"),
+           torch.tensor([64 * 12 + 50, 64 * 33 + 17], dtype=torch.int32, device="cuda")]
+    tr.train_step_graphed(x, sem, ins, n, selected_idx=order_a, injected_s_t=inj)   # first sight of the shapes: eager
     torch.cuda.synchronize()
     snap = _snapshot(m, tr)
 
     def run(step, order):
         _restore(m, tr, snap)
-        out = step(x, sem, ins, n, selected_idx=order)
+        out = step(x, sem, ins, n, selected_idx=order, injected_s_t=inj)
         torch.cuda.synchronize()
         return m.store.flat.clone(), m.store.grad.clone(), [float(v) for v in out["head"]], dict(m.store.int_buffers)
 
