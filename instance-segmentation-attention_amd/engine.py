@@ -733,6 +733,22 @@ class Engine:
             self.tape.append(bwd)
         return lazy
 
+    def act_out(self, raw: Act, act, out: Act) -> Act:
+        """Materialised activation out = act(raw) for consumers that would re-evaluate a lazy prologue many
+        times (a 3x3 conv applies it once per tap: tanh ahead of attend_fc cost 9 tanhf per element)."""
+        lazy = raw.with_pro(Pro(act=act))
+        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), None, None, None, out.d(), self.st()),
+                "isa_affine_act_res(act)")
+        if self.record:
+            def bwd():
+                acc = self.grads.claim(raw, self)
+                assert acc == 0, "act_out expects to be the only consumer of its input"
+                L.check(self.lib.isa_bn_bwd_apply(self.grads.grad_of(out).d(), raw.d(), None, None, None, None, act,
+                                                  None, None, None, 1.0, 0, self.grads.grad_of(raw).d(), None, None,
+                                                  self.st()), "isa_bn_bwd_apply(act_out)")
+            self.tape.append(bwd)
+        return out
+
     def materialize(self, x: Act, out: Act, res: Optional[Act] = None):
         """out = pro(x) (+res) for a lazy x that is NOT a BN output (bias+act convs)."""
         L.check(self.lib.isa_affine_act_res(x.d(), x.p(), res.d() if res is not None else None, None, None,

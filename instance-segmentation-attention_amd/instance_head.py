@@ -121,7 +121,8 @@ class InstanceHead:
         e1 = E.new_act(n, h, w, 12)
         E.conv(sp, pre + ".l1.weight", e1, bias=pre + ".l1.bias")
         e2 = E.new_act(n, h, w, 1)
-        E.conv(E.act(e1, L.ACT_TANH), pre + ".attend_fc.1.weight", e2, taps=9, bias=pre + ".attend_fc.1.bias")
+        e1t = E.act_out(e1, L.ACT_TANH, E.new_act(n, h, w, 12))        # tanh once, not once per tap
+        E.conv(e1t, pre + ".attend_fc.1.weight", e2, taps=9, bias=pre + ".attend_fc.1.bias")
         am, v, mean_var = E.f32(2 * n), E.f32(n), E.f32(2)
         train = 1 if E.bn_train else 0
         rm, rv = P.ptr(pre + ".bn.running_mean"), P.ptr(pre + ".bn.running_var")
