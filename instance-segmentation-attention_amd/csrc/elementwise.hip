@@ -372,6 +372,40 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(Pool3Params p) {
     }
 }
 
+// vector form for C % 8 == 0: an item is (pixel, 8-channel group), nine 16-byte loads, 32-bit index math
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3_vec_kernel(Pool3Params p) {
+    const unsigned cg = (unsigned)p.y.c / 8, W = (unsigned)p.y.w, H = (unsigned)p.y.h;
+    const unsigned items = (unsigned)p.y.n * H * W * cg;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < items; i += gridDim.x * 256u) {
+        const unsigned c0 = (i % cg) * 8; unsigned q = i / cg;
+        const int xo = (int)(q % W); q /= W;
+        const int yo = (int)(q % H); const int b = (int)(q / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = yo + dy, xx = xo + dx;
+                if (yy >= 0 && yy < p.x.h && xx >= 0 && xx < p.x.w) {
+                    float v[8];
+                    load8<T>(reinterpret_cast<const T*>(p.x.data) + (((long)b * p.x.h + yy) * p.x.w + xx) * p.x.ld + c0, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+            }
+        const long pix = ((long)b * p.y.h + yo) * p.y.w + xo;
+        float m = 1.f / 9.f;
+        if (p.has_mask) m *= st<T>::ld(reinterpret_cast<const T*>(p.mask.data) + pix * p.mask.ld);
+        T* o = reinterpret_cast<T*>(p.y.data) + pix * p.y.ld + c0;
+        float old[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.accumulate) load8<T>(o, old);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * m + old[j];
+        store8<T>(o, acc);
+    }
+}
+
 // per-(image,channel) mean of pro(x): grid = (blocks, n)
 struct MeanParams { View x; ProDev pro; float* out; float inv_hw; };
 template <typename T>
@@ -641,6 +675,15 @@ extern "C" int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const i
     if (mask && (!tensor_ok(mask, 1) || mask->n != x->n || mask->h != x->h || mask->w != x->w ||
                  mask->dtype != x->dtype)) return ISA_EINVAL;
     Pool3Params p{mkview(x), mask ? mkview(mask) : View{}, mkview(y), mask != nullptr, accumulate};
+    const long vec_items = (long)y->n * y->h * y->w * (y->c / 8);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x->data) % 16 == 0) && (reinterpret_cast<uintptr_t>(y->data) % 16 == 0);
+    if (y->c % 8 == 0 && x->ld % 8 == 0 && y->ld % 8 == 0 && aligned && vec_items < (1L << 31)) {
+        const int gridv = grid_cap(cdiv(vec_items, 256), 256 * 16);
+        DISPATCH_T(x->dtype,
+            hipLaunchKernelGGL(avgpool3_vec_kernel<bf16_t>, dim3(gridv), dim3(256), 0, as_stream(stream), p),
+            hipLaunchKernelGGL(avgpool3_vec_kernel<float>, dim3(gridv), dim3(256), 0, as_stream(stream), p));
+        return launch_status();
+    }
     const int grid = grid_cap(cdiv((long)y->n * y->h * y->w * y->c, 256));
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(avgpool3_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), p),

@@ -392,28 +392,43 @@ __device__ __forceinline__ void bil_src(int o, int n_in, int& i0, int& i1, float
     if (s < 0.f) s = 0.f;
     i0 = (int)s; i1 = min(i0 + 1, n_in - 1); w1 = s - (float)i0;
 }
-template <typename T>
-__global__ __launch_bounds__(256) void gate_bwd_hi_kernel(View dout, View up, const float* gmap, View dup, int accumulate, float* du) {
+// POW2: the channel-group count is a power of two <= 64, so the lanes of one pixel are adjacent in a wave: the
+// per-pixel dot product is folded with shuffles and stored once (no atomics, shift/mask instead of 64-bit
+// division).  Otherwise one float atomic per lane into the zeroed du.
+template <typename T, bool POW2>
+__global__ __launch_bounds__(256) void gate_bwd_hi_kernel(View dout, View up, const float* gmap, View dup, int accumulate, float* du, int sh) {
     const int C = up.c, cg = (C + 7) / 8;
     const long pixels = (long)up.n * up.h * up.w;
-    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < pixels * cg; item += (long)gridDim.x * 256) {
-        const int c0 = (int)(item % cg) * 8; const long pix = item / cg;
-        const int nv = min(8, C - c0);
-        float d[8], u[8], o[8];
-        load8g<T>(reinterpret_cast<const T*>(dout.data) + pix * dout.ld + c0, d, nv);
-        load8g<T>(reinterpret_cast<const T*>(up.data) + pix * up.ld + c0, u, nv);
-        const float g = gmap[pix];
-        float acc = 0.f;
+    const long total = pixels * cg;
+    for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+        const long item = base + threadIdx.x;
+        const bool live = item < total;
+        int c0 = 0; long pix = 0;
+        if (POW2) { c0 = (int)(item & (cg - 1)) * 8; pix = item >> sh; }
+        else { c0 = (int)(item % cg) * 8; pix = item / cg; }
+        float acc = 0.f, g = 0.f;
+        if (live) {
+            const int nv = min(8, C - c0);
+            float d[8], u[8], o[8];
+            load8g<T>(reinterpret_cast<const T*>(dout.data) + pix * dout.ld + c0, d, nv);
+            load8g<T>(reinterpret_cast<const T*>(up.data) + pix * up.ld + c0, u, nv);
+            g = gmap[pix];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { if (c0 + j < C) acc += d[j] * u[j]; o[j] = d[j] * g; }
-        T* dst = reinterpret_cast<T*>(dup.data) + pix * dup.ld + c0;
-        if (accumulate) {
-            float old[8]; load8g<T>(dst, old, nv);
+            for (int j = 0; j < 8; ++j) { if (c0 + j < C) acc += d[j] * u[j]; o[j] = d[j] * g; }
+            T* dst = reinterpret_cast<T*>(dup.data) + pix * dup.ld + c0;
+            if (accumulate) {
+                float old[8]; load8g<T>(dst, old, nv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += old[j];
+                for (int j = 0; j < 8; ++j) o[j] += old[j];
+            }
+            store8g<T>(dst, o, nv);
         }
-        store8g<T>(dst, o, nv);
-        atomicAdd(du + pix, acc * g * (1.f - g));
+        if (POW2) {
+            for (int off = 1; off < cg; off <<= 1) acc += __shfl_xor(acc, off, 64);
+            if (live && c0 == 0) du[pix] = acc * g * (1.f - g);
+        } else if (live) {
+            atomicAdd(du + pix, acc * g * (1.f - g));
+        }
     }
 }
 template <typename T>
@@ -671,9 +686,18 @@ extern "C" int isa_gate_bwd(const isa_tensor* dout, const isa_tensor* up, const 
     hipStream_t s = as_stream(stream);
     const long items = (long)up->n * up->h * up->w * ((up->c + 7) / 8);
     const int g1 = grid_cap(cdiv(items, 256)), g2 = grid_cap(cdiv((long)dpred->n * dpred->h * dpred->w, 256));
-    DISPATCH_T(up->dtype,
-        hipLaunchKernelGGL(gate_bwd_hi_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du),
-        hipLaunchKernelGGL(gate_bwd_hi_kernel<float>, dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du));
+    const int cgs = (up->c + 7) / 8;
+    int sh = 0;
+    while ((1 << sh) < cgs) ++sh;
+    if ((1 << sh) == cgs && cgs <= 64) {
+        DISPATCH_T(up->dtype,
+            hipLaunchKernelGGL((gate_bwd_hi_kernel<bf16_t, true>), dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du, sh),
+            hipLaunchKernelGGL((gate_bwd_hi_kernel<float, true>), dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du, sh));
+    } else {
+        DISPATCH_T(up->dtype,
+            hipLaunchKernelGGL((gate_bwd_hi_kernel<bf16_t, false>), dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du, sh),
+            hipLaunchKernelGGL((gate_bwd_hi_kernel<float, false>), dim3(g1), dim3(256), 0, s, mkview(dout), mkview(up), gmap, mkview(dup), acc_up, du, sh));
+    }
     DISPATCH_T(up->dtype,
         hipLaunchKernelGGL(gate_bwd_lo_kernel<bf16_t>, dim3(g2), dim3(256), 0, s, du, up->h, up->w, mkview(dpred), acc_pred),
         hipLaunchKernelGGL(gate_bwd_lo_kernel<float>, dim3(g2), dim3(256), 0, s, du, up->h, up->w, mkview(dpred), acc_pred));
