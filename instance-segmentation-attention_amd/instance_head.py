@@ -218,8 +218,8 @@ class InstanceHead:
         hmid = E.new_act(n, h, w, out_ch // 2)
         E.conv(x5, pre + ".pred.l_i.weight", hmid, taps=9, bias=pre + ".pred.l_i.bias")
         pred = E.new_act(n, h, w, 2)
-        E.conv(E.act(hmid, L.ACT_LEAKY), pre + ".pred.last_fc.1.weight", pred, taps=9,
-               bias=pre + ".pred.last_fc.1.bias")
+        hact = E.act_out(hmid, L.ACT_LEAKY, E.new_act(n, h, w, out_ch // 2))     # once, not once per tap
+        E.conv(hact, pre + ".pred.last_fc.1.weight", pred, taps=9, bias=pre + ".pred.last_fc.1.bias")
         return x5, pred
 
     def _block_ir_ext(self, x, pre, out, res2=None, oscale=None):
