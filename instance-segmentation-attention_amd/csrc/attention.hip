@@ -396,7 +396,7 @@ extern "C" int isa_mask_dot(const isa_tensor* x, const float* m, const float* w,
                             float* dot, float* chansum, void* stream) {
     if (!tensor_ok(x, 8) || !m || !w || !bias || !dot || !chansum) return ISA_EINVAL;
     const long items = (long)x->h * x->w * ((x->c + 7) / 8);
-    dim3 grid(grid_cap(cdiv(items, 256), 256), x->n);
+    dim3 grid(grid_keep_cg(grid_cap(cdiv(items, 256), 256), (x->c + 7) / 8), x->n);
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(mask_dot_kernel<bf16_t>, grid, dim3(256), x->c * 4, as_stream(stream), mkview(x), m, w, bias, dot, chansum),
         hipLaunchKernelGGL(mask_dot_kernel<float>, grid, dim3(256), x->c * 4, as_stream(stream), mkview(x), m, w, bias, dot, chansum));
@@ -415,7 +415,7 @@ extern "C" int isa_sp_softmax(const float* dot, const float* m, const float* cha
 extern "C" int isa_scaled_stats(const isa_tensor* x, const float* beta, float* stats, void* stream) {
     if (!tensor_ok(x, 8) || !beta || !stats) return ISA_EINVAL;
     const long items = (long)x->n * x->h * x->w * ((x->c + 7) / 8);
-    const int grid = grid_cap(cdiv(items, 256));
+    const int grid = grid_keep_cg(grid_cap(cdiv(items, 256), 1024), (x->c + 7) / 8);
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(scaled_stats_kernel<bf16_t>, dim3(grid), dim3(256), 2 * x->c * 4, as_stream(stream), mkview(x), beta, stats),
         hipLaunchKernelGGL(scaled_stats_kernel<float>, dim3(grid), dim3(256), 2 * x->c * 4, as_stream(stream), mkview(x), beta, stats));

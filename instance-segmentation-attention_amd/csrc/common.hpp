@@ -151,5 +151,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// For `item = pixel*cg + channel_group` grid-stride loops: round the grid so that the stride (grid*256) is a multiple
+// of cg.  A lane then keeps ONE channel group for its whole life and its per-channel partial sums are flushed
+// once, not on every trip (cg = 3 for the 24-channel attention tensors: 2048*256 % 3 != 0 flushed every trip).
+static inline int grid_keep_cg(int grid, int cg) {
+    int m = cg;
+    while (m % 2 == 0) m /= 2;                       // 256 already supplies the powers of two
+    if (m <= 1 || grid < m) return grid;
+    return grid - grid % m;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }

@@ -663,7 +663,7 @@ extern "C" int isa_sp_bwd(const isa_tensor* dout, const isa_tensor* x, const flo
     p.out_red = red; p.dbeta_map = dbeta; p.gw = gw;
     hipStream_t s = as_stream(stream);
     const long items = (long)n * L * ((C + 7) / 8);
-    const int grid = grid_cap(cdiv(items, 256));
+    const int grid = grid_keep_cg(grid_cap(cdiv(items, 256)), (C + 7) / 8);
     if (train)
         DISPATCH_T(x->dtype,
             hipLaunchKernelGGL(sp_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 2 * C * 4, s, p),

@@ -107,6 +107,8 @@ class Trainer:
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")
             return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
+        if slot["state"] == "eager":
+            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
         if slot["state"] == "warm":
             slot["x"] = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
             slot["sem"] = torch.empty(tuple(sem.shape), dtype=sem.dtype, device=dev)
@@ -117,11 +119,20 @@ class Trainer:
             self._stage(slot, x, sem, ins, selected_idx, max_iter, injected_s_t)
             before = dict(st.int_buffers)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
-                                            injected_s_t=slot["inj"])
-                if self.world == 1:
-                    self.apply_update()
+            try:
+                with torch.cuda.graph(g):
+                    out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
+                                                injected_s_t=slot["inj"])
+                    if self.world == 1:
+                        self.apply_update()
+            except Exception as e:                 # capture refused (driver / collective state): stay eager, loudly
+                import sys
+                print("[isa_amd] hipGraph capture failed (%s: %s); this configuration runs eagerly" %
+                      (type(e).__name__, e), file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                st.int_buffers.update(before)
+                slot["state"] = "eager"
+                return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
             # capture only records: undo its host-side counters, replay() below performs the step
             slot["bumps"] = {k: v - before[k] for k, v in st.int_buffers.items() if v != before[k]}
             st.int_buffers.update(before)
