@@ -26,6 +26,19 @@ struct Dw2Params {
     float* ws; int csrc;
 };
 
+// 8 storage elements kept packed in registers (4 VGPRs for bf16) until they are consumed
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
+};
+template <> struct raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+
 // per-lane prologue constants: a lane stages the same 8-channel group on every iteration (i += 256 keeps i & 3)
 struct ProRegs { float sc[8], sh[8], bs[8]; };
 
@@ -96,85 +109,171 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
 }
 
-template <typename T, bool HAS_PRO, int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void dw2_fwd_kernel(Dw2Params p) {
+// Persistent over tiles of one channel block.  DB (bf16): 512 threads, waves 4-7 stage the next tile into the other
+// LDS buffer while waves 0-3 run the stencil on the current one (the same role split as dw_bn_bwd_kernel below);
+// weights, prologue constants and the statistic partial sums live across tiles and are flushed once.
+template <typename T, bool HAS_PRO, int ACT, bool DB>
+__global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 3))) void dw2_fwd_kernel(Dw2Params p) {
+    constexpr int NTHR = DB ? 512 : 256;
+    constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* tile = sm;                       // [HALO][PS]
-    float* wts = sm + HALO * PS;            // [9][CB]
-    float* red = wts + 9 * CB;              // [2*CB]
-    const int tid = threadIdx.x;
+    float* tile_base = sm;                          // [NBUF][HALO][PS]
+    float* wts = sm + NBUF * HALO * PS;             // [9][CB]
+    float* red = wts + 9 * CB;                      // [2*CB]
+    const int tid = threadIdx.x, ltid = tid & 255;
+    const bool loader = DB && tid >= 256;
     const int c_base = blockIdx.y * CB;
-    const long t = blockIdx.x;
-    const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
-    const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
     const T* wp = reinterpret_cast<const T*>(p.w);
-    for (int i = tid; i < 9 * CB; i += 256) {
+    for (int i = tid; i < 9 * CB; i += NTHR) {
         const int tp = i / CB, cc = i - tp * CB;
         wts[i] = (c_base + cc < p.c) ? st<T>::ld(wp + (long)tp * p.wld + c_base + cc) : 0.f;
     }
     if (tid < 2 * CB) red[tid] = 0.f;
-    ProRegs pr;
-    load_pro<HAS_PRO>(p, pr, c_base + (tid & 3) * 8, b);
-    stage_tile<T, HAS_PRO, ACT>(p, pr, tile, b, ty, tx, c_base);
-    __syncthreads();
-
-    const int cg = tid & 3, g = tid >> 2, row = g >> 3, x0 = (g & 7) * 4;
+    const int cg = ltid & 3, g = ltid >> 2, row = g >> 3, x0 = (g & 7) * 4;
     const int c0 = c_base + cg * 8;
-    float acc[4][8];
+    const bool cok = c0 < p.c;
+    const T* xin = reinterpret_cast<const T*>(p.x);
+    constexpr int NIT = (HALO * 4 + 255) / 256;
+
+    auto stage = [&](long t, float* tile) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+        float sc[8], sh[8], bs[8];
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(c0 + j, p.c - 1);
+            sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
+            sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
+            bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + c] : 1.f;
+        }
+        raw8<T> v[NIT]; bool ok[NIT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[o][j] = (p.bias && c0 + j < p.c) ? p.bias[c0 + j] : 0.f;
-#pragma unroll 1
-    for (int dy = 0; dy < 3; ++dy) {
-        float wr[3][8], in[6][8];
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (ltid + it * 256) >> 2;
+            const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+            const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
+            ok[it] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
+            if (ok[it]) v[it].load(xin + (((long)b * p.h + gy) * p.w_ + gx) * p.ldx + c0);
+        }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ld8(wts + (dy * 3 + k) * CB + cg * 8, wr[k]);
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (ltid + it * 256) >> 2;
+            if (pix >= HALO) continue;
+            float o[8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ld8(tile + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+            for (int j = 0; j < 8; ++j) {
+                float z = 0.f;
+                if (ok[it]) {
+                    z = v[it].get(j);
+                    if constexpr (HAS_PRO) {
+                        z = act_t<ACT>(fmaf(z, sc[j], sh[j]), p.pro.act);
+                        if (p.pro.bscale) z *= bs[j];
+                    }
+                }
+                o[j] = z;
+            }
+            store8<float>(tile + pix * PS + cg * 8, o);
+        }
+    };
+
+    auto compute = [&](long t, const float* tile, float (&s1)[8], float (&s2)[8]) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+        const int oy = ty * TH + row;
+        raw8<T> oc[4];
+        if (p.accumulate && oy < p.h && cok) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int ox = tx * TW + x0 + o;
+                if (ox < p.w_) oc[o].load(reinterpret_cast<const T*>(p.y) + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0);
+            }
+        }
+        float acc[4][8];
 #pragma unroll
         for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                fma8(in[o + k], wr[k], acc[o]);
-    }
-    const int oy = ty * TH + row;
-    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (oy < p.h && c0 < p.c) {
-        T* yout = reinterpret_cast<T*>(p.y);
+            for (int j = 0; j < 8; ++j) acc[o][j] = (p.bias && c0 + j < p.c) ? p.bias[c0 + j] : 0.f;
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+            float wr[3][8], in[6][8];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int ox = tx * TW + x0 + o;
-            if (ox >= p.w_) continue;
-            T* dst = yout + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0;
+            for (int k = 0; k < 3; ++k) ld8(wts + (dy * 3 + k) * CB + cg * 8, wr[k]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
-            if (p.accumulate) {
-                float old[8]; load8<T>(dst, old);
+            for (int k = 0; k < 6; ++k) ld8(tile + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o][j] += old[j];
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    fma8(in[o + k], wr[k], acc[o]);
+        }
+        if (oy < p.h && cok) {
+            T* yout = reinterpret_cast<T*>(p.y);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int ox = tx * TW + x0 + o;
+                if (ox >= p.w_) continue;
+                T* dst = yout + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] += oc[o].get(j);
+                }
+                store8<T>(dst, acc[o]);
             }
-            store8<T>(dst, acc[o]);
         }
-    }
-    if (p.stats) {
-        // lanes with equal (lane & 3) share a channel group: fold the 16 of them, then 4 LDS atomics per wave
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
-        }
-        if ((tid & 63) < 4) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&red[cg * 8 + j], s1[j]); atomicAdd(&red[CB + cg * 8 + j], s2[j]); }
-        }
+    };
+
+    __syncthreads();                                             // weights + zeroed `red` visible
+    if (loader) {
+        long t = blockIdx.x;
+        int buf = 0;
+        if (t < p.ntiles) stage(t, tile_base);
         __syncthreads();
-        if (tid < 2 * CB) {
-            const int cc = tid & (CB - 1), which = tid / CB;
-            if (c_base + cc < p.c && red[tid] != 0.f) {
-                float* rep = p.stats + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
-                atomicAdd(rep + which * p.c + c_base + cc, red[tid]);
+        for (; t < p.ntiles; t += gridDim.x) {
+            const long tn = t + gridDim.x;
+            if (tn < p.ntiles) stage(tn, tile_base + (buf ^ 1) * HALO * PS);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (DB) {
+            long t = blockIdx.x;
+            int buf = 0;
+            __syncthreads();
+            for (; t < p.ntiles; t += gridDim.x) {
+                compute(t, tile_base + buf * HALO * PS, s1, s2);
+                __syncthreads();
+                buf ^= 1;
             }
+        } else {
+            for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+                stage(t, tile_base);
+                __syncthreads();
+                compute(t, tile_base, s1, s2);
+                __syncthreads();
+            }
+        }
+        if (p.stats) {
+            // lanes with equal (lane & 3) share a channel group: fold the 16 of them, then 4 LDS atomics per wave
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+            }
+            if ((tid & 63) < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { atomicAdd(&red[cg * 8 + j], s1[j]); atomicAdd(&red[CB + cg * 8 + j], s2[j]); }
+            }
+        }
+    }
+    __syncthreads();
+    if (p.stats && tid < 2 * CB) {
+        const int cc = tid & (CB - 1), which = tid / CB;
+        if (c_base + cc < p.c && red[tid] != 0.f) {
+            float* rep = p.stats + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.c;
+            atomicAdd(rep + which * p.c + c_base + cc, red[tid]);
         }
     }
 }
@@ -269,17 +368,34 @@ __global__ __launch_bounds__(256) void dw2_wgrad_reduce_kernel(const float* ws, 
     }
 }
 
+template <typename T, bool HAS_PRO, int ACT>
+int launch_fwd2_inst(Dw2Params& p, dim3 grid, hipStream_t s) {
+    constexpr bool DB = sizeof(T) == 2;
+    constexpr size_t lds = ((size_t)(DB ? 2 : 1) * HALO * PS + 9 * CB + 2 * CB) * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_fwd_kernel<T, HAS_PRO, ACT, DB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISA_ELAUNCH;
+        configured = true;
+    }
+    hipLaunchKernelGGL((dw2_fwd_kernel<T, HAS_PRO, ACT, DB>), grid, dim3(DB ? 512 : 256), lds, s, p);
+    return launch_status();
+}
+
 template <typename T>
 int launch_fwd2(Dw2Params& p, bool has_pro, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
     if (p.ntiles >= (1L << 31)) return ISA_EINVAL;
-    dim3 grid((unsigned)p.ntiles, (p.c + CB - 1) / CB);
-    const size_t lds = ((size_t)HALO * PS + 9 * CB + 2 * CB) * 4;
-    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw2_fwd_kernel<T, true, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
-    else if (has_pro) hipLaunchKernelGGL((dw2_fwd_kernel<T, true, ACT_RT>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((dw2_fwd_kernel<T, false, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
-    return launch_status();
+    const int ncb = (p.c + CB - 1) / CB;
+    // persistent: bf16 = one 512-thread double-buffered workgroup per CU, f32 = three 256-thread ones
+    long gx = (256L * (sizeof(T) == 2 ? 1 : 3)) / ncb;
+    if (gx < 1) gx = 1;
+    if (gx > p.ntiles) gx = p.ntiles;
+    dim3 grid((unsigned)gx, ncb);
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) return launch_fwd2_inst<T, true, ISA_ACT_RELU6>(p, grid, s);
+    if (has_pro) return launch_fwd2_inst<T, true, ACT_RT>(p, grid, s);
+    return launch_fwd2_inst<T, false, ISA_ACT_NONE>(p, grid, s);
 }
 
 template <typename T>
@@ -321,19 +437,6 @@ struct FusedParams {
     int accumulate, tiles_x, tiles_y; long ntiles; float* ws; int csrc; float* dw;
 };
 
-
-// 8 storage elements kept packed in registers (4 VGPRs for bf16) until they are consumed
-template <typename T> struct raw8;
-template <> struct raw8<bf16_t> {
-    bf16x8 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
-    __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
-};
-template <> struct raw8<float> {
-    f32x4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
-    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
-};
 
 template <typename T> struct dd_stride { static constexpr int v = 36; };       // floats: 144 B / pixel
 template <> struct dd_stride<bf16_t> { static constexpr int v = 40; };         // 80 B / pixel: 4 x-groups tile 256 B

@@ -155,12 +155,22 @@ class InstanceHead:
         return merge
 
     # ------------------------------------------------------------------ pyramid decoder
+    def _draw_masks(self, n, max_iter, training):
+        """All Dropout2d masks of a step from ONE torch.rand draw (3 per level and iteration: utils.py:869-892).
+        Per-mask draws were ~120 five-microsecond launches per step."""
+        self._mask_pool, self._mask_cursor = None, 0
+        if self.drop_rate <= 0 or not (training or self.E.bn_train):
+            return
+        total = max_iter * sum(3 * n * oc for oc in OUT_CH)
+        keep = 1.0 - self.drop_rate
+        self._mask_pool = (torch.rand(total, device=self.E.device) < keep).float() / keep   # host-side RNG plumbing
+
     def _drop_mask(self, n, c, active):
         if not active or self.drop_rate <= 0:
             return None
-        keep = 1.0 - self.drop_rate
-        m = (torch.rand(n, c, device=self.E.device) < keep).float() / keep      # host-side RNG plumbing
-        return m.contiguous()
+        m = self._mask_pool[self._mask_cursor:self._mask_cursor + n * c].view(n, c)
+        self._mask_cursor += n * c
+        return m
 
     def level(self, lvl, x_prev: Act, skip: Act, pred_prev: Act, mask_all, s_t, W_full, training, masks):
         """One UpDecoderLayer (utils.py:869-892).  Returns (x, pred)."""
@@ -272,6 +282,7 @@ class InstanceHead:
             self.baseline = torch.zeros(1, dtype=torch.float32, device=E.device)
         if capture is not None:
             capture.update(x_enc=x_enc, s_sp=s, merge=merge)
+        self._draw_masks(n, max_iter, training)
         for it in range(max_iter):
             idx = idx_dev[it]
             alpha, rowstat = E.f32(n * Lp), E.f32(2 * n)
