@@ -120,7 +120,8 @@ class Trainer:
             before = dict(st.int_buffers)
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                # thread_local: the RCCL watchdog thread may query events while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
                                                 injected_s_t=slot["inj"])
                     if self.world == 1:
