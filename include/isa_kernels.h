@@ -144,12 +144,14 @@ int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const is
 /* The same fusion for a bias-free 1x1 convolution y = W x (W fp32 [N][K], state_dict layout) followed by a
  * train-mode BatchNorm2d (MobileNetDenseASPP.py:105-107,113-114 expand / project; :81-82 InvertedV1):
  *   dy = BN-backward(g, y; ybn);  dw += dy^T . pro(x);  dx (+)= dy . W;  xbn as above.
+ * `addend` (optional, shape of x): dx += addend, e.g. the gradient arriving through the block's residual branch
+ * (saves the separate accumulate pass).
  * bf16 storage only, N <= 64, K <= 64, both multiples of 8; otherwise ISA_EINVAL (callers then use
  * isa_bn_bwd_apply + isa_conv_wgrad + isa_conv_gemm).                                               */
 int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                             const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                             const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
-                            float* ws, int64_t ws_floats, void* stream);
+                            const isa_tensor* addend, float* ws, int64_t ws_floats, void* stream);
 
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the

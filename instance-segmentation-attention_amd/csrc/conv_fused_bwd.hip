@@ -26,6 +26,7 @@ struct PwParams {
     const float *ysc, *ysh, *ymu, *yis, *yred; float ycnt_inv; int yact; float *ydgamma, *ydbeta;
     const float *xsc, *xsh, *xmu, *xis; int xact; float* xred;
     int accumulate; float* ws;
+    const bf16_t* addend; int lda;       // optional: dx += addend (the residual branch's gradient, saves its axpy pass)
 };
 
 // XMODE 0: plain x; 1: x = relu6(scale*x+shift) with BN(x) sums produced; 2: runtime prologue, sums if p.xred
@@ -209,6 +210,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)o[j] + (float)old[j]);
                 }
+                if (p.addend) {
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(p.addend + m * p.lda + ck0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)o[j] + (float)ad[j]);
+                }
                 *reinterpret_cast<bf16x8*>(dst) = o;
                 if (want_xred) {
 #pragma unroll
@@ -279,7 +285,7 @@ int launch_inst(PwParams& p, long ws_floats, hipStream_t s) {
     const long nchunks = (p.M + 31) / 32;
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long gx = (nchunks + 3) / 4;
-    if (gx > 256 * 3) gx = 256 * 3;
+    if (gx > 256 * 2) gx = 256 * 2;                                  // 2 resident workgroups per CU; fewer slabs to reduce
     const long ws_cap = ws_floats / slabf;
     if (ws_cap < 1) return ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
@@ -305,7 +311,7 @@ int launch_tile(PwParams& p, int xmode, long ws_floats, hipStream_t s) {
 extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                                        const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                                        const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
-                                       float* ws, int64_t ws_floats, void* stream) {
+                                       const isa_tensor* addend, float* ws, int64_t ws_floats, void* stream) {
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (g->dtype != ISA_BF16 || y->dtype != ISA_BF16 || x->dtype != ISA_BF16 || dx->dtype != ISA_BF16) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
@@ -328,6 +334,11 @@ extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y,
     p.xsc = xp.scale; p.xsh = xp.shift; p.xact = xp.act;
     p.xmu = xbn ? xbn->mean : nullptr; p.xis = xbn ? xbn->invstd : nullptr; p.xred = xbn ? xbn->out_red : nullptr;
     p.accumulate = accumulate; p.ws = ws;
+    if (addend) {
+        if (!tensor_ok(addend, 8) || addend->dtype != ISA_BF16 || addend->c != K || addend->n != g->n || addend->h != g->h ||
+            addend->w != g->w) return ISA_EINVAL;
+        p.addend = (const bf16_t*)addend->data; p.lda = addend->ld;
+    }
     int xmode = 0;
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
     hipStream_t s = as_stream(stream);

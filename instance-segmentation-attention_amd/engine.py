@@ -383,6 +383,7 @@ class Engine:
         # the same for bias-free 1x1 convs with <= 64 channels either side (isa_conv1x1_bn_backward, bf16 only)
         self.fuse_pw_bn = os.environ.get("ISA_FUSE_PW_BN", "1") != "0"
         self._pw_out: Dict[tuple, dict] = {}
+        self._pw_in: Dict[tuple, dict] = {}      # conv input -> the same records: residual gradients ride along
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool):
@@ -391,6 +392,7 @@ class Engine:
         self.tape = []
         self._dw_out = {}
         self._pw_out = {}
+        self._pw_in = {}
         self.bn_train, self.record = bn_train, record
         self.stats_cursor = 0
         if self.stats is not None:
@@ -469,13 +471,20 @@ class Engine:
                     and out.c % 8 == 0 and x.c % 8 == 0 and (x.pro is None or x.pro.bscale is None):
                 xb = getattr(x, "bn", None)
                 ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
-                info = dict(xbn=xb if ok_x else None, ybn=None)
+                info = dict(xbn=xb if ok_x else None, ybn=None, addend=None, done=False)
                 self._pw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
+                self._pw_in[(x.buf.data_ptr(), x.c0, x.c)] = info
 
             def bwd():
-                if info is not None and info["ybn"] is not None:
-                    self._fused_pw_backward(x, wname, info)
-                    return
+                if info is not None:
+                    info["done"] = True
+                    if info["ybn"] is not None:
+                        self._fused_pw_backward(x, wname, info)
+                        return
+                    if info["addend"] is not None:        # deferred residual gradient, conv ended up unfused
+                        acc0 = self.grads.claim(x, self)
+                        L.check(self.lib.isa_axpy(info["addend"].d(), self.grads.grad_of(x).d(), 1.0, acc0, self.st()),
+                                "isa_axpy(res, deferred)")
                 dy = self.grads.grad_of(out)
                 pk = self.packer
                 if transposed:
@@ -533,6 +542,7 @@ class Engine:
         L.check(self.lib.isa_conv1x1_bn_backward(
             g.d(), yb["raw"].d(), C.byref(ydesc), x.d(), x.p(), C.byref(xdesc) if xdesc is not None else None,
             self.params.ptr(wname), self.params.gptr(wname), self.grads.grad_of(x).d(), acc,
+            info["addend"].d() if info["addend"] is not None else None,
             L.ptr(self.ws), self.ws.numel(), self.st()), "isa_conv1x1_bn_backward")
 
     def _launch_conv(self, x, reg, bias, out, in_mode, out_mode, st):
@@ -709,6 +719,10 @@ class Engine:
                     L.check(self.lib.isa_scale_bc(dout.d(), L.ptr(oscale), dsum.d(), 0, self.st()), "isa_scale_bc")
                 for r in (res, res2):
                     if r is not None and r.needs_grad:
+                        pin = self._pw_in.get((r.buf.data_ptr(), r.c0, r.c))
+                        if pin is not None and not pin["done"] and pin["addend"] is None:
+                            pin["addend"] = dsum          # the consuming 1x1 conv's backward adds it to dx itself
+                            continue
                         acc = self.grads.claim(r, self)
                         L.check(self.lib.isa_axpy(dsum.d(), self.grads.grad_of(r).d(), 1.0, acc, self.st()),
                                 "isa_axpy(res)")
