@@ -147,7 +147,7 @@ def main():
     log("%.2f ms/step, %.1f img/s" % (ms, value))
 
     out = {
-        "metric": "images/sec @256x256 bs=16 per GPU",
+        "metric": "images/sec @%dx%d bs=%d per GPU" % (S, S, B),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
