@@ -322,7 +322,7 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     // workgroups on the chip (the re-read A operand is L2-resident at these sizes): 4096 px x 512 ch ran as 128
     // workgroups on 256 CUs.
     const long tiles_m = (p.M + 127) / 128;
-    while (nt > 1 && tiles_m * ((p.N + 32 * nt - 1) / (32 * nt)) < 256) nt /= 2;
+    while (nt > 1 && tiles_m * ((p.N + 32 * nt - 1) / (32 * nt)) < 512) nt /= 2;
     const int n_blk = 32 * nt;
     // weight chunk sized to <= 48 KB of LDS
     int gpc = (48 * 1024) / (n_blk * 32 * (int)sizeof(T));

@@ -547,7 +547,12 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
         if (grid > cap) grid = cap;
         if (grid < 1) grid = 1;
     } else {
-        grid = walk_grid(wk, 16);
+        // 16 trips per workgroup on the big tensors (amortises the O(C) epilogue); on the small ones fewer trips
+        // so that at least ~512 workgroups exist (64x64x16 px x 64 ch ran as 128 workgroups of 16 serial trips)
+        const long per = 256 >> wk.sh;
+        int iters = 16;
+        if (cdiv(p.pixels, per * 16) < 512) { iters = (int)(p.pixels / (per * 512)); if (iters < 2) iters = 2; }
+        grid = walk_grid(wk, iters);
         if (!apply && grid > 1024) grid = 1024;     // every block ends with 2C global atomics (8 replicas)
     }
     const size_t lds = 2 * (size_t)y->c * 4;
