@@ -160,6 +160,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (chunk + stride < nchunks) fetch(chunk + stride);
+        // operands of this chunk's store epilogue (old dx / residual-branch gradient): requested now, consumed after
+        // the MFMAs, so their latency is not exposed at the end of the trip
+        constexpr bool EPI_PREFETCH = TK == 1;                    // wider x tiles have no registers to spare
+        bf16x8 repi_old[EPI_PREFETCH ? LOADS_K : 1], repi_add[EPI_PREFETCH ? LOADS_K : 1];
+        if constexpr (EPI_PREFETCH) {
+            const long mb = chunk * PMB;
+#pragma unroll
+            for (int v = 0; v < LOADS_K; ++v) {
+                const long m = mb + v * RPK + rowk;
+                repi_old[v] = bf16x8{0}; repi_add[v] = bf16x8{0};
+                if (m < p.M && kok) {
+                    if (p.accumulate) repi_old[v] = *reinterpret_cast<const bf16x8*>(p.dx + m * p.lddx + ck0);
+                    if (p.addend) repi_add[v] = *reinterpret_cast<const bf16x8*>(p.addend + m * p.lda + ck0);
+                }
+            }
+        }
         // ---- weight gradient
 #pragma unroll
         for (int s = 0; s < PMB / 16; ++s) {
@@ -206,12 +222,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 bf16x8 o = *reinterpret_cast<const bf16x8*>(sX + (v * RPK + rowk) * SK + cgk * 16);
                 bf16_t* dst = p.dx + m * p.lddx + ck0;
                 if (p.accumulate) {
-                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+                    bf16x8 old;
+                    if constexpr (EPI_PREFETCH) old = repi_old[v]; else old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)o[j] + (float)old[j]);
                 }
                 if (p.addend) {
-                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(p.addend + m * p.lda + ck0);
+                    bf16x8 ad;
+                    if constexpr (EPI_PREFETCH) ad = repi_add[v]; else ad = *reinterpret_cast<const bf16x8*>(p.addend + m * p.lda + ck0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)o[j] + (float)ad[j]);
                 }
