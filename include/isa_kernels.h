@@ -288,6 +288,11 @@ int isa_local_attention(const isa_tensor* q, const isa_tensor* k, const isa_tens
 /* a21 Decoder.forward (utils.py:59-69): out[b,p] = sigmoid(<q[b,:], enc[b,p,:]>) */
 int isa_point_query(const float* q, const isa_tensor* enc, float* out, void* stream);
 
+/* ---- input expansion: ImageEx + ToTensor + Standardization, code/lib/utils.py:90-113 and
+ * code/lib/preprocess.py:192-195.  rgb: uint8 [n,h,w,3] (device); out: NHWC view with c == 21 (ld 24: the three pad
+ * channels are written as zero).  out = ([rgb, lab, hsv, yuv, ycbcr, hed, yiq] - 0.5) * 2.                     */
+int isa_image_ex(const uint8_t* rgb, const isa_tensor* out, void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);

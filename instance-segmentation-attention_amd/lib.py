@@ -96,6 +96,7 @@ SIGNATURES = {
     "isa_sdp_attention": [VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, VP],
     "isa_local_attention": [P_T, P_T, P_T, VP, P_T, I32, VP],
     "isa_point_query": [VP, P_T, VP, VP],
+    "isa_image_ex": [VP, P_T, VP],
     "isa_nchw_to_nhwc": [VP, I32, P_T, VP],
     "isa_nhwc_to_nchw": [P_T, VP, VP],
 }

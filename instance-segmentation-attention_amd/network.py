@@ -163,6 +163,26 @@ class Network:
         L.check(E.lib.isa_nchw_to_nhwc(L.ptr(x), c, dst.d(), E.st()), "isa_nchw_to_nhwc")
         return dst
 
+    def image_ex(self, rgb: torch.Tensor) -> Act:
+        """uint8 RGB [n,h,w,3] -> the 21-channel standardized NHWC input (ImageEx + ToTensor + Standardization,
+        lib/utils.py:90-113, preprocess.py:192-195) in one kernel; replaces the six skimage conversions per image
+        of the reference's data pipeline (parity unpinned, see oracle/image_ex_ref.py)."""
+        E = self.E
+        assert rgb.dtype == torch.uint8 and rgb.dim() == 4 and rgb.shape[-1] == 3, "expects uint8 [n,h,w,3]"
+        n, h, w, _ = rgb.shape
+        rgb = rgb.to(E.device).contiguous()
+        dst = E.new_act(n, h, w, 21, ld=24)
+        dst.needs_grad = False
+        self._keep = rgb
+        L.check(E.lib.isa_image_ex(L.ptr(rgb), dst.d(), E.st()), "isa_image_ex")
+        return dst
+
+    def input_view(self, x: torch.Tensor) -> Act:
+        """Network input: the reference's [n,21,h,w] float tensor, or raw uint8 RGB [n,h,w,3] expanded on device."""
+        if x.dtype == torch.uint8:
+            return self.image_ex(x)
+        return self.to_nhwc(x.to(device=self.E.device, dtype=torch.float32))
+
     def to_nchw(self, a: Act) -> torch.Tensor:
         E = self.E
         out = torch.empty((a.n, a.c, a.h, a.w), dtype=torch.float32, device=a.buf.device)

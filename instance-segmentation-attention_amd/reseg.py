@@ -143,15 +143,19 @@ class ReSeg(nn.Module):
             x, sem_seg_target, ins_seg_target, N = _input
         else:
             x = _input[0]
-        assert x.dim() == 4 and x.shape[1] == 21, "expects [B,21,H,W] (ImageEx tensor, utils.py:109)"
-        assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
+        raw_rgb = x.dtype == torch.uint8           # [B,H,W,3] uint8: ImageEx runs on device (net.image_ex)
+        if raw_rgb:
+            assert x.dim() == 4 and x.shape[3] == 3, "uint8 input must be RGB [B,H,W,3]"
+            assert x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0
+        else:
+            assert x.dim() == 4 and x.shape[1] == 21, "expects [B,21,H,W] (ImageEx tensor, utils.py:109)"
+            assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
         dev = self.store.device
-        x = x.to(device=dev, dtype=torch.float32)
         E.begin(bn_train=self.training, record=False)
         if getattr(self, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         self._weights_dirty = False
-        xin = net.to_nhwc(x)
+        xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
         sem = net.sem_head(x_dec)
         sem_out = net.to_nchw(sem)

@@ -33,7 +33,7 @@ class Trainer:
         m = self.model
         E, net, st = m.engine, m.net, m.store
         dev = st.device
-        x = x.to(device=dev, dtype=torch.float32)
+        x = x.to(device=dev) if x.dtype == torch.uint8 else x.to(device=dev, dtype=torch.float32)
         sem = sem.to(dev).contiguous()
         ins = ins.to(dev).contiguous()
         st.grad[:st.n_train].zero_()
@@ -41,7 +41,7 @@ class Trainer:
         if getattr(m, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         m._weights_dirty = False
-        xin = net.to_nhwc(x)
+        xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
         sem_a = net.sem_head(x_dec)
         sem_scal = net.sem_loss(sem_a, sem)
@@ -102,7 +102,7 @@ class Trainer:
                 random.shuffle(order)
                 selected_idx.append(order)
         key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
-               m.engine.dtype, injected_s_t is not None)
+               m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8)
         slot = self._graphs.get(key)
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")
@@ -110,7 +110,8 @@ class Trainer:
         if slot["state"] == "eager":
             return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
         if slot["state"] == "warm":
-            slot["x"] = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
+            slot["x"] = torch.empty(tuple(x.shape), dtype=torch.uint8 if x.dtype == torch.uint8 else torch.float32,
+                                    device=dev)
             slot["sem"] = torch.empty(tuple(sem.shape), dtype=sem.dtype, device=dev)
             slot["ins"] = torch.empty(tuple(ins.shape), dtype=ins.dtype, device=dev)
             slot["idx"] = torch.zeros((max(max_iter, 1), x.shape[0]), dtype=torch.int32, device=dev)
