@@ -115,7 +115,10 @@ def main():
         model.eval()
 
         def step():
-            model(False, x)
+            if args.no_graph:
+                model(False, x)
+            else:
+                model.infer_graphed(x)      # hipGraph replay of the same launches (reseg.py)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -123,7 +126,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if workload == "train_step" and not args.no_graph:
+    if workload in ("train_step", "infer") and not args.no_graph:
         log("graph setup: one eager step + one capture step (untimed, before the warmup steps)")
         step()
         step()
@@ -155,14 +158,19 @@ def main():
             {"train_step": "train.py step fwd+bwd+update", "train_fwd": "ReSeg.forward(training) conv+attention head",
              "infer": "pred_list batched inference"}[workload], S, S, B, args.dtype),
             "global_batch": world * B, "image": [S, S], "parallelism": "dp%d" % world,
-            "launch": "eager" if (args.no_graph or workload != "train_step") else "hipGraph replay"},
+            "launch": "eager" if (args.no_graph or workload == "train_fwd") else "hipGraph replay"},
     }
 
     if rank == 0:
         # ---- roofline: one extra instrumented step, events on the launch stream -----------------
         E = model.engine
         E.profile = True
-        (eager_step if workload == "train_step" else step)()      # per-launch events need the eager launch loop
+        if workload == "train_step":                              # per-launch events need the eager launch loop
+            eager_step()
+        elif workload == "infer":
+            model(False, x)
+        else:
+            step()
         prof = E.profile_summary()
         E.profile = False
         fam = {k: v for k, v in prof.items() if v[2] > 0}
