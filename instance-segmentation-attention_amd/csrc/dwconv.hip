@@ -305,7 +305,10 @@ int dw_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const flo
                const isa_tensor* y, float* stats, int accumulate, void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(y, 8) || !w || x->dtype != y->dtype) return ISA_EINVAL;
     if (x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) return ISA_EINVAL;
-    if (x->c % 8 == 0) return dw2_forward(x, pro, w, bias, y, stats, accumulate, stream);
+    // the tiled kernels work on whole 8-channel vectors: views whose row pitch covers rup(C,8) qualify (the 21-channel
+    // input lives in 24-channel rows; pad lanes compute garbage that no consumer reads and no statistic sees)
+    const int c8 = (x->c + 7) / 8 * 8;
+    if (x->ld >= c8 && y->ld >= c8) return dw2_forward(x, pro, w, bias, y, stats, accumulate, stream);
     DwParams p{};
     p.x = x->data; p.w = w; p.bias = bias; p.y = y->data;
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldy = y->ld;
@@ -356,7 +359,8 @@ extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, cons
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (x->n != dy->n || x->h != dy->h || x->w != dy->w || x->c != dy->c) return ISA_EINVAL;
     if (!ws) return ISA_EINVAL;
-    if (x->c % 8 == 0) return dw2_wgrad(x, pro, dy, dw, dbias, csrc, ws, ws_floats, stream);
+    const int c8 = (x->c + 7) / 8 * 8;
+    if (x->ld >= c8 && dy->ld >= c8) return dw2_wgrad(x, pro, dy, dw, dbias, csrc, ws, ws_floats, stream);
     if (10 * (size_t)x->c * 4 > 60 * 1024) return ISA_EINVAL;
     DwWgParams p{};
     p.x = x->data; p.dy = dy->data; p.dw = dw; p.dbias = dbias;
