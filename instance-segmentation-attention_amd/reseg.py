@@ -123,11 +123,13 @@ class ReSeg(nn.Module):
             self.store.int_buffers[name] = int(mod._buffers[leaf])
         self.engine.packer.table = None if self.engine.packer.entries else self.engine.packer.table
         self._weights_dirty = True
+        self.engine.eval_bn_cache.clear()
         return out
 
     def mark_weights_dirty(self):
         """Call after an optimizer step changed the flat parameter buffer (repack on next forward)."""
         self._weights_dirty = True
+        self.engine.eval_bn_cache.clear()
 
     # ------------------------------------------------------------------ hipGraph-replayed GT-free inference
     def infer_graphed(self, x):
