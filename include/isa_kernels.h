@@ -134,11 +134,12 @@ typedef struct isa_bn_bwd {
  *   xbn != NULL: xbn->out_red += sums of BN(x)'s backward over the finished dx
  *                (isa_bn_bwd_reduce of the layer that produced x; requires dx to be complete, i.e.
  *                every other consumer of x has already accumulated into it).
+ * addend (optional, shape of x): dx += addend - the gradient arriving through the block's residual branch.
  * g, y, x, dx: same shape and dtype, C % 8 == 0; xpro without bscale; ybn->red already reduced.     */
 int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                               const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                               const void* w_flipped, float* dw, int32_t csrc,
-                              const isa_tensor* dx, int32_t accumulate,
+                              const isa_tensor* dx, int32_t accumulate, const isa_tensor* addend,
                               float* ws, int64_t ws_floats, void* stream);
 
 /* The same fusion for a bias-free 1x1 convolution y = W x (W fp32 [N][K], state_dict layout) followed by a

@@ -435,6 +435,7 @@ struct FusedParams {
     const float *ysc, *ysh, *ymu, *yis, *yred; float ycnt_inv; int yact; float *ydgamma, *ydbeta;
     const float *xsc, *xsh, *xmu, *xis; int xact; float* xred;
     int accumulate, tiles_x, tiles_y; long ntiles; float* ws; int csrc; float* dw;
+    const void* addend; int lda;      // optional: dx += addend (gradient of the block's residual branch)
 };
 
 
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         const int oy = ty * TH + row;
         // operands of the epilogue (old dx for accumulate, raw x for the BN(x) sums) are requested before the
         // stencil so their latency hides behind it: a compute wave has no sibling wave to switch to
-        raw8<T> xc[4], oc[4];
+        raw8<T> xc[4], oc[4], ad[4];
         if (oy < p.h && cok) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 const long po = ((long)b * p.h + oy) * p.w_ + ox;
                 if (want_xred) xc[o].load(xin + po * p.ldx + c0);
                 if (p.accumulate) oc[o].load(dxo + po * p.lddx + c0);
+                if constexpr (XMODE == 0) { if (p.addend) ad[o].load(reinterpret_cast<const T*>(p.addend) + po * p.lda + c0); }
             }
         }
         {   // ---- data gradient: dx tile = flipped taps over dy (halo), then BN(x)-backward sums
@@ -623,6 +625,12 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                     if (p.accumulate) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) a[o][j] += oc[o].get(j);
+                    }
+                    if constexpr (XMODE == 0) {              // plain-tensor input: the only case with a residual branch
+                        if (p.addend) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a[o][j] += ad[o].get(j);
+                        }
                     }
                     store8<T>(dst, a[o]);
                     if (want_xred) {
@@ -801,7 +809,7 @@ int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, flo
 extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                                          const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                                          const void* w_flipped, float* dw, int32_t csrc,
-                                         const isa_tensor* dx, int32_t accumulate,
+                                         const isa_tensor* dx, int32_t accumulate, const isa_tensor* addend,
                                          float* ws, int64_t ws_floats, void* stream) {
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
@@ -822,6 +830,12 @@ extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* 
     p.xsc = xp.scale; p.xsh = xp.shift; p.xact = xp.act;
     p.xmu = xbn ? xbn->mean : nullptr; p.xis = xbn ? xbn->invstd : nullptr; p.xred = xbn ? xbn->out_red : nullptr;
     p.accumulate = accumulate; p.ws = ws; p.dw = dw;
+    if (addend) {
+        if (!tensor_ok(addend, 8) || addend->dtype != g->dtype || addend->c != g->c || addend->n != g->n || addend->h != g->h ||
+            addend->w != g->w) return ISA_EINVAL;
+        p.addend = addend->data; p.lda = addend->ld;
+        if (!pro_trivial(make_pro(xpro)) || xbn) return ISA_EINVAL;      // only for a plain-tensor x
+    }
     p.csrc = (csrc > 0 && csrc < g->c) ? csrc : g->c;
     int xmode = 0;
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;

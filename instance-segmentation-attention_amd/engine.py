@@ -596,12 +596,20 @@ class Engine:
                 # so every other consumer of x has already accumulated its gradient when we run
                 xb = getattr(x, "bn", None)
                 ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
-                info = dict(xbn=xb if ok_x else None, ybn=None)
+                info = dict(xbn=xb if ok_x else None, ybn=None, addend=None, done=False)
                 self._dw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
+                if x.pro is None and xb is None:                                  # plain tensor: residual gradients may ride along
+                    self._pw_in.setdefault((x.buf.data_ptr(), x.c0, x.c), info)
 
             def bwd():
                 dy = self.grads.grad_of(out)
                 nb = x.n * x.h * x.w * x.c * x.buf.element_size()
+                if info is not None:
+                    info["done"] = True
+                    if info["ybn"] is None and info["addend"] is not None:    # deferred residual gradient, unfused after all
+                        acc0 = self.grads.claim(x, self)
+                        L.check(self.lib.isa_axpy(info["addend"].d(), self.grads.grad_of(x).d(), 1.0, acc0, self.st()),
+                                "isa_axpy(res, deferred)")
                 if info is not None and info["ybn"] is not None:
                     yb, yred = info["ybn"]
                     xb = info["xbn"]
@@ -618,6 +626,7 @@ class Engine:
                         dy.d(), yb["raw"].d(), C.byref(ydesc), x.d(), x.p(),
                         C.byref(xdesc) if xdesc is not None else None, self.packer.ptr(reg["dgrad"]),
                         self.params.gptr(wname), self.params.shapes[wname][0], self.grads.grad_of(x).d(), acc,
+                        info["addend"].d() if info["addend"] is not None else None,
                         L.ptr(self.ws), self.ws.numel(), self.st()), "isa_dwconv3x3_bn_backward")
                     return
                 if self.profile:

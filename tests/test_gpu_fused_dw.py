@@ -68,7 +68,8 @@ def _reference(kind, dtype, x, dy, t):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind,cin,chid,cout,h,w", [("ir", 16, 96, 16, 12, 20), ("ir", 32, 48, 24, 9, 37),
                                                      ("ir", 32, 64, 32, 16, 16), ("ir", 64, 64, 64, 8, 24),
-                                                     ("v1", 64, 64, 32, 16, 16), ("v1", 40, 40, 16, 7, 33)])
+                                                     ("v1", 64, 64, 32, 16, 16), ("v1", 40, 40, 16, 7, 33),
+                                                     ("v1", 32, 32, 32, 12, 20)])      # residual gradient rides along
 def test_fused_dw_bn_backward(dtype, kind, cin, chid, cout, h, w):
     n = 3
     t = {}
