@@ -20,6 +20,9 @@
 //     (exact fp32 FMA chain) — used for the 1e-3 parity mode.
 #include "common.hpp"
 
+int conv3x3_tiled_launch(const isa_tensor* x, const void* w, const float* bias, const isa_tensor* y, int accumulate,
+                         hipStream_t s);          // conv3x3_tiled.hip: narrow dense 3x3 convs from an LDS halo tile
+
 namespace {
 
 struct GemmParams {
@@ -378,6 +381,9 @@ extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void
     p.M = (long)x->n * p.mh * p.mw;
     if (p.M >= (1L << 31)) return ISA_EINVAL;
     const bool has_pro = !pro_trivial(p.pro);
+    if (in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && !has_pro && !stats && kp == 32 &&
+        y->c <= 32)
+        return conv3x3_tiled_launch(x, w, bias, y, accumulate, as_stream(stream));
     if (x->dtype == ISA_BF16) return launch0<bf16_t>(p, has_pro, in_mode, out_mode, as_stream(stream));
     return launch0<float>(p, has_pro, in_mode, out_mode, as_stream(stream));
 }
