@@ -5,6 +5,9 @@
 // 10x off the HBM time).  Here the (8+2) x (32+2) input halo tile is staged ONCE in LDS and the nine taps are nine
 // shifted `ds_read_b128` row reads feeding v_mfma_f32_32x32x16_bf16; the 9 x kp x N weights live in registers.
 #include "common.hpp"
+#include "tr_lds.hpp"
+
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s);
 
 namespace {
 
@@ -137,4 +140,138 @@ int conv3x3_tiled_launch(const isa_tensor* x, const void* w, const float* bias, 
     const size_t lds = (size_t)HALO * XS + 4 * 32 * 33 * 4;
     hipLaunchKernelGGL(conv3x3_tiled_kernel, dim3((unsigned)gx), dim3(256), lds, s, p);
     return launch_status();
+}
+
+// ---- weight gradient of the same convs: dW[n][k][tap] += sum_px dy[px][n] * x[px + tap][k] -----------------------
+// One pass: the x halo tile and the dy tile are staged once; every 16-pixel step fetches ONE dy fragment and nine
+// shifted x fragments (ds_read_b64_tr_b16: the contraction index is the pixel) for nine MFMAs.  The generic kernel
+// runs nine tap slices that each re-read x and dy.
+namespace {
+
+constexpr int WS_ = 64;                        // bytes per staged pixel (32 bf16), both tiles
+
+struct C3WParams {
+    const bf16_t* x; const bf16_t* dy; int n, h, w, cin, ldx, N, ldd;
+    float* ws; int tiles_x, tiles_y; long ntiles;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tiled_kernel(C3WParams p) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* xt = sm;                              // [HALO][64 B]
+    char* dt = sm + HALO * WS_;                 // [TH*TW][64 B]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int cg = tid & 3, c0 = cg * 8;
+    const int xvalid = max(0, min(8, p.cin - c0)), dvalid = max(0, min(8, p.N - c0));
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x16{0};
+    float dbs = 0.f;
+
+    for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
+        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+        __syncthreads();
+        constexpr int NIT = (HALO * 4 + 255) / 256;
+        bf16x8 v[NIT], d[4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 2;
+            const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+            const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
+            v[it] = bf16x8{0};
+            if (pix < HALO && xvalid > 0 && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
+                v[it] = *reinterpret_cast<const bf16x8*>(p.x + (((long)b * p.h + gy) * p.w + gx) * p.ldx + c0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pix = (tid + it * 256) >> 2;                    // 0..255: (row, col) of the output tile
+            const int gy = ty * TH + (pix >> 5), gx = tx * TW + (pix & 31);
+            d[it] = bf16x8{0};
+            if (dvalid > 0 && gy < p.h && gx < p.w)
+                d[it] = *reinterpret_cast<const bf16x8*>(p.dy + (((long)b * p.h + gy) * p.w + gx) * p.ldd + c0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 2;
+            if (pix >= HALO) continue;
+            bf16x8 o = v[it];
+            if (xvalid < 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j >= xvalid) o[j] = (bf16_t)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(xt + pix * WS_ + c0 * 2) = o;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pix = (tid + it * 256) >> 2;
+            bf16x8 o = d[it];
+            if (dvalid < 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j >= dvalid) o[j] = (bf16_t)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(dt + pix * WS_ + c0 * 2) = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = wave * 2 + half;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = tr_frag(dt, WS_, row * TW + 16 * s, 0, lane);            // A[n][pixel]
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dbs += (float)a[j];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int dy = tp / 3, dx = tp % 3;
+                    const bf16x8 bfr = tr_frag(xt, WS_, (row + dy) * (TW + 2) + 16 * s + dx, 0, lane);   // B[pixel][k]
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[tp], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- fold the four waves, one slab set per workgroup: [tap][1024 fragment floats + 32 bias sums]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sm);
+    constexpr int ACC_FLOATS = 9 * 1024;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* qd = red + (tp * 16 + e) * 64 + lane;
+                    *qd = (w == 0 ? 0.f : *qd) + acc[tp][e];
+                }
+            const float sv = dbs + __shfl_xor(dbs, 32, 64);
+            if (hh == 0) { float* qd = red + ACC_FLOATS + r; *qd = (w == 0 ? 0.f : *qd) + sv; }
+        }
+        __syncthreads();
+    }
+    constexpr int SLABF = 1024 + 32;
+    for (int i = tid; i < 9 * SLABF; i += 256) {
+        const int tp = i / SLABF, idx = i - tp * SLABF;
+        float val = idx < 1024 ? red[tp * 1024 + idx] : (tp == 0 ? red[ACC_FLOATS + idx - 1024] : 0.f);
+        p.ws[((long)blockIdx.x * 9 + tp) * SLABF + idx] = val;
+    }
+}
+
+}  // namespace
+
+int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float* dw, float* dbias, float* ws, long ws_floats,
+                               hipStream_t s) {
+    C3WParams p{};
+    p.x = (const bf16_t*)x->data; p.dy = (const bf16_t*)dy->data; p.n = x->n; p.h = x->h; p.w = x->w;
+    p.cin = x->c; p.ldx = x->ld; p.N = dy->c; p.ldd = dy->ld; p.ws = ws;
+    p.tiles_x = (p.w + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
+    long gx = p.ntiles < 512 ? p.ntiles : 512;
+    const long cap = ws_floats / (9L * (1024 + 32));
+    if (cap < 1) return ISA_EINVAL;
+    if (gx > cap) gx = cap;
+    const size_t tiles = (size_t)HALO * WS_ + (size_t)TH * TW * WS_, redb = (9 * 1024 + 32) * 4;
+    const size_t lds = tiles > redb ? tiles : redb;
+    hipLaunchKernelGGL(conv3x3_wgrad_tiled_kernel, dim3((unsigned)gx), dim3(256), lds, s, p);
+    if (launch_status() != ISA_OK) return ISA_ELAUNCH;
+    return wgrad_slab_reduce_launch(ws, dw, dbias, (int)gx, 1, 1, p.N, p.cin, 9, s);
 }

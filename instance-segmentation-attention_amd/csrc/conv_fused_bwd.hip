@@ -16,7 +16,7 @@
 #include "common.hpp"
 #include "tr_lds.hpp"
 
-int wgrad_slab_reduce_launch(float* ws, float* dw, int gx, int tn, int tk, int N, int cin, hipStream_t s);
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s);
 
 namespace {
 
@@ -309,7 +309,7 @@ int launch_inst(PwParams& p, long ws_floats, hipStream_t s) {
     if (gx > ws_cap) gx = ws_cap;
     hipLaunchKernelGGL((pw_bn_bwd_kernel<TN, TK, YACT, XMODE>), dim3((unsigned)gx), dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;
-    return wgrad_slab_reduce_launch(p.ws, p.dw, (int)gx, TN, TK, p.N, p.K, s);
+    return wgrad_slab_reduce_launch(p.ws, p.dw, nullptr, (int)gx, TN, TK, p.N, p.K, 1, s);
 }
 
 template <int TN, int TK>

@@ -19,6 +19,9 @@
 #include "common.hpp"
 #include "tr_lds.hpp"
 
+int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float* dw, float* dbias, float* ws, long ws_floats,
+                               hipStream_t s);     // conv3x3_tiled.hip
+
 namespace {
 
 constexpr int PM = 16;          // pixels per wave-chunk (8 MFMA k-steps)
@@ -550,6 +553,9 @@ extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa
         p.taps = in_mode == ISA_IN_3X3 ? 9 : 1; p.N = dy->c;
     }
     p.nchunks = (p.M + PM - 1) / PM;
+    if (in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && pro_trivial(p.pro) && !kmap &&
+        x->c <= 32 && dy->c <= 32 && p.ksrc == x->c)
+        return conv3x3_wgrad_tiled_launch(x, dy, dw, dbias, ws, ws_floats, as_stream(stream));
     if (x->dtype == ISA_BF16) return dispatch_wg<bf16_t>(p, as_stream(stream));
     return dispatch_wg<float>(p, as_stream(stream));
 }
@@ -591,10 +597,11 @@ extern "C" int isa_colsum(const isa_tensor* x, float* out, void* stream) {
     return launch_status();
 }
 
-// second-stage reduction for other translation units that write conv_wgrad-format slabs (conv_fused_bwd.hip)
-int wgrad_slab_reduce_launch(float* ws, float* dw, int gx, int tn, int tk, int N, int cin, hipStream_t s) {
+// second-stage reduction for other translation units that write conv_wgrad-format slabs (conv_fused_bwd.hip,
+// conv3x3_tiled.hip): one tile group, `taps` slab sets per workgroup
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s) {
     WgParams p{};
-    p.ws = ws; p.dw = dw; p.dbias = nullptr; p.kmap = nullptr; p.taps = 1; p.groups_k = 1; p.N = N; p.cin = cin;
+    p.ws = ws; p.dw = dw; p.dbias = dbias; p.kmap = nullptr; p.taps = taps; p.groups_k = 1; p.N = N; p.cin = cin;
     p.ksrc = cin; p.out_mode = ISA_OUT_PLAIN;
     return launch_reduce(p, gx, 1, tn, tk, s);
 }
