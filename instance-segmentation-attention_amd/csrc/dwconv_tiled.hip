@@ -109,6 +109,21 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
 }
 
+// XCD-aware tile walk for the persistent kernels: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its
+// own L2.  Adjacent tiles share halo rows / columns, so each XCD gets ONE contiguous eighth of the tile sequence and
+// its workgroups stride inside it: the halo overlap is re-read from that XCD's L2 instead of from seven other ones.
+struct TileRange { long t0, end, step; };
+__device__ __forceinline__ TileRange tile_range(long ntiles) {
+    const int G = gridDim.x;
+    if ((G & 7) == 0 && ntiles >= 64) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const long chunk = (ntiles + 7) / 8;
+        const long end = min(ntiles, (xcd + 1) * chunk);
+        return TileRange{xcd * chunk + j, end, (long)(G >> 3)};
+    }
+    return TileRange{(long)blockIdx.x, ntiles, (long)G};
+}
+
 // Persistent over tiles of one channel block.  DB (bf16): 512 threads, waves 4-7 stage the next tile into the other
 // LDS buffer while waves 0-3 run the stencil on the current one (the same role split as dw_bn_bwd_kernel below);
 // weights, prologue constants and the statistic partial sums live across tiles and are flushed once.
@@ -226,23 +241,25 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 
     __syncthreads();                                             // weights + zeroed `red` visible
     if (loader) {
-        long t = blockIdx.x;
+        const TileRange tr = tile_range(p.ntiles);
+        long t = tr.t0;
         int buf = 0;
-        if (t < p.ntiles) stage(t, tile_base);
+        if (t < tr.end) stage(t, tile_base);
         __syncthreads();
-        for (; t < p.ntiles; t += gridDim.x) {
-            const long tn = t + gridDim.x;
-            if (tn < p.ntiles) stage(tn, tile_base + (buf ^ 1) * HALO * PS);
+        for (; t < tr.end; t += tr.step) {
+            const long tn = t + tr.step;
+            if (tn < tr.end) stage(tn, tile_base + (buf ^ 1) * HALO * PS);
             __syncthreads();
             buf ^= 1;
         }
     } else {
         float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (DB) {
-            long t = blockIdx.x;
+            const TileRange tr = tile_range(p.ntiles);
+            long t = tr.t0;
             int buf = 0;
             __syncthreads();
-            for (; t < p.ntiles; t += gridDim.x) {
+            for (; t < tr.end; t += tr.step) {
                 compute(t, tile_base + buf * HALO * PS, s1, s2);
                 __syncthreads();
                 buf ^= 1;
@@ -673,13 +690,14 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // max(loader set, compute set) instead of their sum.  Both sides execute the same number of barriers.
     __syncthreads();                                             // constants + zeroed `red` visible
     if (loader) {
-        long t = blockIdx.x;
+        const TileRange tr = tile_range(p.ntiles);
+        long t = tr.t0;
         int buf = 0;
-        if (t < p.ntiles) stage(t, xt_base, dt_base);
+        if (t < tr.end) stage(t, xt_base, dt_base);
         __syncthreads();                                         // first tile staged
-        for (; t < p.ntiles; t += gridDim.x) {
-            const long tn = t + gridDim.x;
-            if (tn < p.ntiles) stage(tn, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
+        for (; t < tr.end; t += tr.step) {
+            const long tn = t + tr.step;
+            if (tn < tr.end) stage(tn, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
             __syncthreads();
             buf ^= 1;
         }
@@ -692,10 +710,11 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
         if constexpr (DB) {
-            long t = blockIdx.x;
+            const TileRange tr = tile_range(p.ntiles);
+            long t = tr.t0;
             int buf = 0;
             __syncthreads();                                     // first tile staged
-            for (; t < p.ntiles; t += gridDim.x) {
+            for (; t < tr.end; t += tr.step) {
                 compute(t, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
                 __syncthreads();
                 buf ^= 1;
