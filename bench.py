@@ -22,7 +22,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
 # SURVEY.md §8(d) contract figures, bytes per image at 256^2 in bf16 (x2 for fp32 storage)
@@ -64,7 +64,7 @@ def main():
     import torch.distributed as dist
     import isa_amd  # noqa: F401
     from isa_amd.reseg import ReSeg
-    import reseg_ref as R
+    from isa_amd.data import synth_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,9 +87,9 @@ def main():
 
     use_ins = workload != "infer"
     model = ReSeg(2, use_ins, dtype=dtype)
-    model.load_state_dict(R.synth_state_dict(23, use_ins))       # random-init weights (deterministic)
+    model.reset_parameters(seed=23)                              # random-init weights (deterministic)
     B, S = args.batch, args.size
-    x, sem, ins, n = R.synth_batch(B, S, S, seed=100 + rank)     # per-rank shard of the global batch
+    x, sem, ins, n = synth_batch(B, S, S, seed=100 + rank)       # per-rank shard of the global batch
     x, sem, ins = x.cuda(), sem.cuda(), ins.cuda()
     sel = [list(range(int(k))) for k in n.view(-1)]
 
@@ -195,6 +195,9 @@ def main():
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
+            # the ONLY place the oracle is used: the CPU port of the reference path, timed as a baseline
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import reseg_ref as R
             torch.set_num_threads(max(1, min(ncpu, 16)))      # the GPU box gives one GPU a 16-core share
             log("cpu baseline on %d threads" % torch.get_num_threads())
             cb = 2

@@ -1,7 +1,7 @@
 """Kernel micro-benchmarks at the shapes that dominate the train step (event-timed, L2-cold-ish)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 import torch
 import isa_amd  # noqa
 from isa_amd import lib as L

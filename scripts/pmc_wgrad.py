@@ -1,6 +1,6 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 import torch
 import isa_amd  # noqa
 from isa_amd import lib as L

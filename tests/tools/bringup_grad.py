@@ -1,6 +1,6 @@
 """GPU bring-up: full train-step gradients vs oracle autograd (fp64 oracle as truth)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch
 import isa_amd  # noqa

@@ -1,6 +1,6 @@
 """GPU bring-up: full forward with GT (eval + train-BN) vs the CPU oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch
 import isa_amd  # noqa

@@ -1,6 +1,6 @@
 """GPU bring-up: backbone + semantic head vs the CPU oracle (run through gpurun)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch
 import isa_amd  # noqa

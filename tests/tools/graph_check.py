@@ -1,7 +1,7 @@
 """Per-step parameter divergence: eager vs eager (noise floor) and eager vs graph replay."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import isa_amd  # noqa
 from isa_amd.reseg import ReSeg

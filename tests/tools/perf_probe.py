@@ -1,6 +1,6 @@
 """Time the inference forward (backbone + SE + sem head) at the benchmark shape."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch
 import isa_amd  # noqa
