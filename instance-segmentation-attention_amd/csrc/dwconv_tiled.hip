@@ -150,17 +150,22 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const T* xin = reinterpret_cast<const T*>(p.x);
     constexpr int NIT = (HALO * 4 + 255) / 256;
 
+    // per-channel prologue constants: loaded ONCE per lane (they were re-read from global memory at the top of every
+    // tile: a dependent round trip ahead of the tile's own loads); only the per-image scale changes with the tile
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = min(c0 + j, p.c - 1);
+        sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
+        sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
+    }
     auto stage = [&](long t, float* tile) {
         const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
         const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
-        float sc[8], sh[8], bs[8];
+        float bs[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = min(c0 + j, p.c - 1);
-            sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
-            sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
-            bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + c] : 1.f;
-        }
+        for (int j = 0; j < 8; ++j)
+            bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + min(c0 + j, p.c - 1)] : 1.f;
         raw8<T> v[NIT]; bool ok[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
