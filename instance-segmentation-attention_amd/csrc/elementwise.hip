@@ -178,9 +178,22 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
             if (APPLY) store8g<T>(reinterpret_cast<T*>(p.dy.data) + pix * p.dy.ld + c0, out, nv);
         }
         if (!APPLY) {
+            // lanes that differ only above bit `sh` hold the same channel group: fold them inside the wave first, so a
+            // wave issues one LDS atomic per channel instead of 64 >> sh (they all hit the same address and serialise)
+            const int lane = threadIdx.x & 63;
+            if (wk.sh < 6) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nv) { atomicAdd(&red[c0 + j], s0[j]); atomicAdd(&red[C + c0 + j], s1[j]); }
+                for (int j = 0; j < 8; ++j) {
+                    for (int off = 1 << wk.sh; off < 64; off <<= 1) {
+                        s0[j] += __shfl_xor(s0[j], off, 64); s1[j] += __shfl_xor(s1[j], off, 64);
+                    }
+                }
+            }
+            if (wk.sh >= 6 || (lane >> wk.sh) == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nv) { atomicAdd(&red[c0 + j], s0[j]); atomicAdd(&red[C + c0 + j], s1[j]); }
+            }
         }
     }
     if (!APPLY) {
