@@ -136,10 +136,23 @@ __global__ __launch_bounds__(256) void scaled_stats_kernel(View x, const float* 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = v[j] * bb; s0[j] += t; s1[j] += t * t; }
     }
-    if (last >= 0) {
+    {   // a lane keeps one channel group when the stride is a multiple of cg (host: grid_keep_cg): fold per wave
+        const int lane = threadIdx.x & 63;
+        const bool fixed = ((long)gridDim.x * 256) % cg == 0 && cg < 64;
+        const int cfix = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg) * 8;
+        if (fixed) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (last + j < C) { atomicAdd(&red[last + j], s0[j]); atomicAdd(&red[C + last + j], s1[j]); }
+            for (int j = 0; j < 8; ++j) { s0[j] = fold_stride(s0[j], cg, lane); s1[j] = fold_stride(s1[j], cg, lane); }
+            if (lane < cg) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cfix + j < C) { atomicAdd(&red[cfix + j], s0[j]); atomicAdd(&red[C + cfix + j], s1[j]); }
+            }
+        } else if (last >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (last + j < C) { atomicAdd(&red[last + j], s0[j]); atomicAdd(&red[C + last + j], s1[j]); }
+        }
     }
     __syncthreads();
     float* rep = stats + (blockIdx.x & (ISA_STAT_R - 1)) * 2 * C;

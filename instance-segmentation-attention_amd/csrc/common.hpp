@@ -161,5 +161,17 @@ static inline int grid_keep_cg(int grid, int cg) {
     return grid - grid % m;
 }
 
+// In `item = pixel*cg + group` walks whose stride keeps a lane's group fixed (grid_keep_cg), lanes l, l+cg, l+2cg, ...
+// of a wave hold partial sums of the SAME channel group.  Fold them (strided doubling tree, any cg < 64); lanes < cg
+// end up with the wave totals and are the only ones that touch the LDS accumulator: same-address LDS atomics from
+// every lane serialised and dominated these reductions.
+__device__ __forceinline__ float fold_stride(float v, int cg, int lane) {
+    for (int off = cg; off < 64; off <<= 1) {
+        const float t = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += t;
+    }
+    return v;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }

@@ -259,10 +259,23 @@ __global__ __launch_bounds__(256) void sp_bwd_reduce_kernel(SpBwd p) {
             s0[j] += dq; s1[j] += dq * vh;
         }
     }
-    if (last >= 0) {
+    {
+        const int lane = threadIdx.x & 63;
+        const bool fixed = ((long)gridDim.x * 256) % cg == 0 && cg < 64;
+        const int cfix = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg) * 8;
+        if (fixed) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (last + j < C) { atomicAdd(&red[last + j], s0[j]); atomicAdd(&red[C + last + j], s1[j]); }
+            for (int j = 0; j < 8; ++j) { s0[j] = fold_stride(s0[j], cg, lane); s1[j] = fold_stride(s1[j], cg, lane); }
+            if (lane < cg) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cfix + j < C) { atomicAdd(&red[cfix + j], s0[j]); atomicAdd(&red[C + cfix + j], s1[j]); }
+            }
+        } else if (last >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (last + j < C) { atomicAdd(&red[last + j], s0[j]); atomicAdd(&red[C + last + j], s1[j]); }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * C; i += 256)
