@@ -283,13 +283,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
         }
     }
     if (p.stats) {
+        // the four waves of the workgroup are folded in LDS first: one global atomic per channel and workgroup instead
+        // of four (the replicated counters still see gridDim.x / 8 adders each, serialised at the L2)
+        __shared__ float sred[2 * 128];
+        if (tid < 2 * N_BLK) sred[tid] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t * 32 + r;
-            if (hh == 0 && n < p.N) {
+            if (hh == 0) { atomicAdd(&sred[t * 32 + r], st_sum[t]); atomicAdd(&sred[N_BLK + t * 32 + r], st_sq[t]); }
+        }
+        __syncthreads();
+        if (tid < 2 * N_BLK) {
+            const int which = tid / N_BLK, n = n0 + (tid - which * N_BLK);
+            if (n < p.N) {
                 float* rep = p.stats + ((blockIdx.x + blockIdx.y) & (ISA_STAT_R - 1)) * 2 * p.N;
-                atomicAdd(rep + n, st_sum[t]);
-                atomicAdd(rep + p.N + n, st_sq[t]);
+                atomicAdd(rep + which * p.N + n, sred[tid]);
             }
         }
     }
