@@ -47,29 +47,55 @@ __global__ __launch_bounds__(256) void mask_dot_kernel(View x, const float* m, c
     __syncthreads();
     const long hw = (long)x.h * x.w;
     const int cg = (C + 7) / 8;
-    // lane -> (pixel, channel group): consecutive lanes walk consecutive 16-byte pieces of NHWC rows
+    // lane -> (pixel, channel group): consecutive lanes walk consecutive 16-byte pieces of NHWC rows.  The host rounds
+    // the grid so that the stride is a multiple of cg (grid_keep_cg): a lane keeps ONE channel group, and the cg
+    // lanes of a pixel are adjacent.  Uniform trip count (tail lanes idle) so that shuffles see every lane.
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const long total = hw * cg, step = (long)gridDim.x * 256;
+    const bool fixed = step % cg == 0 && cg < 64;
+    const int cfix = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg) * 8;
     int last = -1;
-    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < hw * cg; item += (long)gridDim.x * 256) {
-        const int c0 = (int)(item % cg) * 8; const long pix = item / cg;
-        if (c0 != last && last >= 0) {
+    for (long base = (long)blockIdx.x * 256; base < total; base += step) {
+        const long item = base + threadIdx.x;
+        const bool live = item < total;
+        const int c0 = live ? (int)(item % cg) * 8 : cfix; const long pix = live ? item / cg : 0;
+        if (!fixed && c0 != last && last >= 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { if (last + j < C) atomicAdd(&red[last + j], acc[j]); acc[j] = 0.f; }
         }
         last = c0;
-        float v[8];
-        load8g<T>(reinterpret_cast<const T*>(x.data) + ((long)b * hw + pix) * x.ld + c0, v, min(8, C - c0));
-        const float mm = m[(long)b * hw + pix];
-        float d = 0.f;
+        float part = 0.f;
+        if (live) {
+            float v[8];
+            load8g<T>(reinterpret_cast<const T*>(x.data) + ((long)b * hw + pix) * x.ld + c0, v, min(8, C - c0));
+            const float mm = m[(long)b * hw + pix];
+            float d = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (c0 + j < C) { d = fmaf(w[c0 + j], v[j], d); acc[j] = fmaf(mm, v[j], acc[j]); }
+            for (int j = 0; j < 8; ++j) {
+                if (c0 + j < C) { d = fmaf(w[c0 + j], v[j], d); acc[j] = fmaf(mm, v[j], acc[j]); }
+            }
+            part = mm * d + (c0 == 0 ? bias[0] : 0.f);
         }
-        // combine the cg partial dots of one pixel: they sit in adjacent lanes when cg | 64;
-        // generic path: float atomics on the (zero-initialised) map
-        atomicAdd(dot + (long)b * hw + pix, mm * d + (c0 == 0 ? bias[0] : 0.f));
+        // the cg partial dots of one pixel sit in adjacent lanes: fold them into the group's first lane when the whole
+        // group is inside this wave (one float atomic per pixel instead of cg), otherwise every lane adds its own
+        const int cgi = c0 >> 3;
+        float tot = part;
+        for (int k = 1; k < cg; ++k) { const float t = __shfl_down(part, k, 64); if (cgi == 0) tot += t; }
+        const bool whole = fixed && lane - cgi >= 0 && lane - cgi + cg - 1 < 64;
+        if (live) {
+            if (whole) { if (cgi == 0) atomicAdd(dot + (long)b * hw + pix, tot); }
+            else atomicAdd(dot + (long)b * hw + pix, part);
+        }
     }
-    if (last >= 0) {
+    if (fixed) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fold_stride(acc[j], cg, lane);
+        if (lane < cg) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (cfix + j < C) atomicAdd(&red[cfix + j], acc[j]);
+        }
+    } else if (last >= 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (last + j < C) atomicAdd(&red[last + j], acc[j]);
     }

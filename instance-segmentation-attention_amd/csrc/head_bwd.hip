@@ -370,9 +370,21 @@ __global__ __launch_bounds__(256) void sp_bwd_dx_kernel(SpBwd p) {
         }
         store8g<T>(dst, o, nv);
     }
-    if (last >= 0) {
+    {
+        const int lane = threadIdx.x & 63;
+        const bool fixed = ((long)gridDim.x * 256) % cg == 0 && cg < 64;
+        const int cfix = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg) * 8;
+        if (fixed) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (last + j < C) atomicAdd(&red[last + j], gacc[j]);
+            for (int j = 0; j < 8; ++j) gacc[j] = fold_stride(gacc[j], cg, lane);
+            if (lane < cg) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (cfix + j < C) atomicAdd(&red[cfix + j], gacc[j]);
+            }
+        } else if (last >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (last + j < C) atomicAdd(&red[last + j], gacc[j]);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256)
