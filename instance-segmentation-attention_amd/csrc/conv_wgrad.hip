@@ -221,20 +221,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
 }
 
 // second stage of the weight gradient: dW (+ dbias) += sum over the gx partial slabs
-constexpr int RSPLIT = 16;
 struct WgReduce {
     const float* ws; float* dw; float* dbias; const int32_t* kmap;
     int gx, gy, taps, groups_k, tn, tk, N, cin, ksrc, out_mode;
+    int rsplit;                 // adders per dW address; chosen so that the launch fills the chip
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
-    // grid = (slab elements / 256, tile groups, taps * RSPLIT): each thread folds 1/RSPLIT of the gx slabs
+    // grid = (slab elements / 256, tile groups, taps * rsplit): each thread folds 1/rsplit of the gx slabs
     // of one fragment element (coalesced 256-byte reads, independent loads) and adds it with ONE atomic:
-    // RSPLIT adders per address instead of gx.
+    // rsplit adders per address instead of gx.
     const int slabf = q.tn * q.tk * 1024 + q.tn * 32;
-    const int group = blockIdx.y, tap = blockIdx.z / RSPLIT, split = blockIdx.z % RSPLIT;
+    const int group = blockIdx.y, tap = blockIdx.z / q.rsplit, split = blockIdx.z % q.rsplit;
     const int gn = group / q.groups_k, gk = group % q.groups_k;
     const int n0 = gn * q.tn * 32, k0 = gk * q.tk * 32;
-    const int per = (q.gx + RSPLIT - 1) / RSPLIT;
+    const int per = (q.gx + q.rsplit - 1) / q.rsplit;
     const int b0 = split * per, b1 = min(q.gx, b0 + per);
     if (b0 >= b1) return;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < slabf; idx += gridDim.x * 256) {
@@ -263,9 +263,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
 }
 
 static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipStream_t s) {
-    WgReduce q{p.ws, p.dw, p.dbias, p.kmap, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode};
     const int slabf = tn * tk * 1024 + tn * 32;
-    dim3 grid(cdiv(slabf, 256), gy, p.taps * RSPLIT);
+    // enough splits for >= ~512 workgroups (a 512-slab reduce of one tile group ran as 144), at most 64 adders per
+    // address and never more splits than slabs
+    const long base_blocks = (long)cdiv(slabf, 256) * gy * p.taps;
+    int rsplit = (int)((512 + base_blocks - 1) / base_blocks);
+    if (rsplit > 64) rsplit = 64;
+    if (rsplit > gx) rsplit = gx;
+    if (rsplit < 1) rsplit = 1;
+    WgReduce q{p.ws, p.dw, p.dbias, p.kmap, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode, rsplit};
+    dim3 grid(cdiv(slabf, 256), gy, p.taps * rsplit);
     hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, s, q);
     return launch_status();
 }
