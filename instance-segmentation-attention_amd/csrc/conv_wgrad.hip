@@ -471,7 +471,7 @@ int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
     const long nchunks = (p.M + 31) / 32;
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (nchunks + 3) / 4;
-    long cap = (256L * 3) / ((long)gy * p.taps);
+    long cap = (256L * 2) / ((long)gy * p.taps);
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
     if (ws_cap < 1) return ISA_EINVAL;                    // workspace too small for even one slab set
     if (cap > ws_cap) cap = ws_cap;
