@@ -136,7 +136,7 @@ int conv3x3_tiled_launch(const isa_tensor* x, const void* w, const float* bias, 
     p.wt = (const bf16_t*)w; p.bias = bias; p.y = (bf16_t*)y->data; p.N = y->c; p.ldy = y->ld; p.accumulate = accumulate;
     p.tiles_x = (p.w + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
-    long gx = p.ntiles < 256 * 3 ? p.ntiles : 256 * 3;         // 44 KB of LDS: three resident workgroups per CU
+    long gx = p.ntiles < 256 * 2 ? p.ntiles : 256 * 2;         // register-limited: two resident workgroups per CU
     const size_t lds = (size_t)HALO * XS + 4 * 32 * 33 * 4;
     hipLaunchKernelGGL(conv3x3_tiled_kernel, dim3((unsigned)gx), dim3(256), lds, s, p);
     return launch_status();
@@ -265,7 +265,7 @@ int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float*
     p.cin = x->c; p.ldx = x->ld; p.N = dy->c; p.ldd = dy->ld; p.ws = ws;
     p.tiles_x = (p.w + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
-    long gx = p.ntiles < 512 ? p.ntiles : 512;
+    long gx = p.ntiles < 256 ? p.ntiles : 256;
     const long cap = ws_floats / (9L * (1024 + 32));
     if (cap < 1) return ISA_EINVAL;
     if (gx > cap) gx = cap;
