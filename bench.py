@@ -131,6 +131,13 @@ def main():
         step()
         step()
         sync_all()
+        if workload == "train_step" and trainer.static_inputs():
+            # the synthetic batch is resident in HBM: place it in the graph's own input buffers once, so that a step
+            # is exactly the replay (a real pipeline writes each new batch into these buffers)
+            gx_, gsem_, gins_ = trainer.static_inputs()[0]
+            gx_.copy_(x); gsem_.copy_(sem); gins_.copy_(ins)
+            x, sem, ins = gx_, gsem_, gins_
+            sync_all()
     log("workload=%s dtype=%s world=%d: warmup" % (workload, args.dtype, world))
     for _ in range(args.warmup):
         step()

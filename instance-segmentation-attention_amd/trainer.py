@@ -150,13 +150,23 @@ class Trainer:
         self.last = slot["out"]
         return self.last
 
+    def static_inputs(self):
+        """(x, sem, ins) input buffers of the captured graphs, most recent configuration first: a data pipeline can
+        write the next batch straight into them (H2D or a device-side producer) and pass these same tensors to
+        train_step_graphed, which then replays without any staging copy."""
+        return [(s["x"], s["sem"], s["ins"]) for s in reversed(list(self._graphs.values())) if s.get("state") == "ready"]
+
     def _stage(self, slot, x, sem, ins, selected_idx, max_iter, injected_s_t=None):
         if slot.get("inj") is not None:          # parity runs: glimpse points fixed from outside
             for dst, src in zip(slot["inj"], injected_s_t):
                 dst.copy_(src, non_blocking=True)
-        slot["x"].copy_(x, non_blocking=True)
-        slot["sem"].copy_(sem, non_blocking=True)
-        slot["ins"].copy_(ins, non_blocking=True)
+        # a caller that fills the graph's own input buffers (static_inputs) skips the device-to-device copies
+        if x is not slot["x"]:
+            slot["x"].copy_(x, non_blocking=True)
+        if sem is not slot["sem"]:
+            slot["sem"].copy_(sem, non_blocking=True)
+        if ins is not slot["ins"]:
+            slot["ins"].copy_(ins, non_blocking=True)
         if max_iter > 0:
             n = slot["x"].shape[0]
             slot["idx_pin"].copy_(self.model.head.order_tensor(selected_idx, max_iter, n))
