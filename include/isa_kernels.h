@@ -154,6 +154,19 @@ int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_
                             const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
                             const isa_tensor* addend, float* ws, int64_t ws_floats, void* stream);
 
+/* ---- deferred weight-gradient folds ------------------------------------------------------------
+ * Every weight-gradient entry point above is two-stage: partial slabs in `ws`, then a small fold kernel that adds
+ * them into dw/dbias.  Nothing reads a weight gradient before the optimizer (torch autograd gives the same freedom to
+ * the reference's loss.backward(), train.py:312-322 -> model.py:204-216), so a backward pass may postpone the folds:
+ * between _begin and _flush (same host thread) those entry points ignore their `ws` argument, place their slabs in
+ * `arena` one after the other and record the fold; _flush adds every recorded slab set into its dw/dbias with one
+ * launch per 32 folds (~190 small launches fewer per training step at the BASELINE configuration).  When less than
+ * 64 MB of `arena` is left a call falls back to its own `ws` and folds immediately.  `arena`: fp32, 256-byte
+ * aligned, >= 16M floats; must not be reused before the flush's kernels have run.  n_folds / arena_used (optional)
+ * report what the pass recorded.                                                                             */
+int isa_wgrad_defer_begin(float* arena, int64_t arena_floats);
+int isa_wgrad_defer_flush(void* stream, int32_t* n_folds, int64_t* arena_used);
+
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the
  * backward); updates running_mean/var (momentum, unbiased var) when running_* != NULL.

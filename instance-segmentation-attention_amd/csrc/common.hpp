@@ -175,3 +175,17 @@ __device__ __forceinline__ float fold_stride(float v, int cg, int lane) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }
+
+// ---- deferred slab folds (isa_wgrad_defer_begin / isa_wgrad_defer_flush; defined in conv_wgrad.hip) ----
+// Weight gradients are leaves of the backward graph: nothing reads dW before the optimizer.  While deferral is
+// active the weight-gradient launchers take their partial-slab region from a step arena (defer_ws) and record the
+// second-stage fold (defer_push) instead of launching it; the flush folds every recorded slab set in a handful of
+// launches (descriptors travel as kernel arguments, so a captured hipGraph keeps them by value).
+struct FoldDesc {
+    const float* ws; float* dw; float* dbias; const int32_t* kmap;
+    int kind;                    // 0: MFMA-fragment slabs (conv_wgrad family), 1: depthwise tile slabs [gx][gy][10*tk]
+    int gx, gy, taps, groups_k, tn, tk, N, cin, ksrc, out_mode, rsplit;
+    int first_block, blocks;
+};
+float* defer_ws(float* ws, long* ws_floats);          // arena cursor + remaining floats when deferring, else unchanged
+bool defer_push(FoldDesc d, long used_floats);        // true: recorded, the caller skips its own reduce launch

@@ -262,6 +262,7 @@ int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float*
                                hipStream_t s) {
     C3WParams p{};
     p.x = (const bf16_t*)x->data; p.dy = (const bf16_t*)dy->data; p.n = x->n; p.h = x->h; p.w = x->w;
+    ws = defer_ws(ws, &ws_floats);
     p.cin = x->c; p.ldx = x->ld; p.N = dy->c; p.ldd = dy->ld; p.ws = ws;
     p.tiles_x = (p.w + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;

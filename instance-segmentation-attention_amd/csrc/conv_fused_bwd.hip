@@ -304,6 +304,7 @@ int launch_inst(PwParams& p, long ws_floats, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long gx = (nchunks + 3) / 4;
     if (gx > 256 * 2) gx = 256 * 2;                                  // 2 resident workgroups per CU; fewer slabs to reduce
+    p.ws = defer_ws(p.ws, &ws_floats);
     const long ws_cap = ws_floats / slabf;
     if (ws_cap < 1) return ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;

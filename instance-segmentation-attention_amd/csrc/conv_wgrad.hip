@@ -16,6 +16,7 @@
 //     blockIdx.z = tap (3x3 dense / transposed-conv quadrant).
 // bf16 storage converts to fp32 while staging; exact-fp32 MFMA keeps weight gradients at fp32 accuracy
 // in both storage modes.  (bf16-MFMA + ds_read_b64_tr_b16 variant: DESIGN.md follow-ups.)
+#include <vector>
 #include "common.hpp"
 #include "tr_lds.hpp"
 
@@ -226,22 +227,22 @@ struct WgReduce {
     int gx, gy, taps, groups_k, tn, tk, N, cin, ksrc, out_mode;
     int rsplit;                 // adders per dW address; chosen so that the launch fills the chip
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
-    // grid = (slab elements / 256, tile groups, taps * rsplit): each thread folds 1/rsplit of the gx slabs
-    // of one fragment element (coalesced 256-byte reads, independent loads) and adds it with ONE atomic:
-    // rsplit adders per address instead of gx.
+// one workgroup's share of a fold: block `bx` of the slab elements, tile group `group`, z = tap * rsplit + split.
+// Each thread folds 1/rsplit of the gx slabs of one fragment element (coalesced 256-byte reads, independent
+// loads) and adds it with ONE atomic: rsplit adders per address instead of gx.
+__device__ __forceinline__ void fold_fragments(const WgReduce& q, int bx, int nbx, int group, int z) {
     const int slabf = q.tn * q.tk * 1024 + q.tn * 32;
-    const int group = blockIdx.y, tap = blockIdx.z / q.rsplit, split = blockIdx.z % q.rsplit;
+    const int tap = z / q.rsplit, split = z % q.rsplit;
     const int gn = group / q.groups_k, gk = group % q.groups_k;
     const int n0 = gn * q.tn * 32, k0 = gk * q.tk * 32;
     const int per = (q.gx + q.rsplit - 1) / q.rsplit;
     const int b0 = split * per, b1 = min(q.gx, b0 + per);
     if (b0 >= b1) return;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < slabf; idx += gridDim.x * 256) {
+    for (int idx = bx * 256 + threadIdx.x; idx < slabf; idx += nbx * 256) {
         float s = 0.f;
 #pragma unroll 8
-        for (int bx = b0; bx < b1; ++bx)
-            s += q.ws[(((long)bx * q.gy + group) * q.taps + tap) * slabf + idx];
+        for (int b = b0; b < b1; ++b)
+            s += q.ws[(((long)b * q.gy + group) * q.taps + tap) * slabf + idx];
         if (idx < q.tn * q.tk * 1024) {
             const int lane = idx & 63, e = (idx >> 6) & 15, t = idx >> 10;
             const int i = t / q.tk, j = t - i * q.tk;
@@ -261,6 +262,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
         }
     }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgReduce q) {
+    // grid = (slab elements / 256, tile groups, taps * rsplit)
+    fold_fragments(q, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
+// depthwise tile slabs [gx][ncb][10*cb] (dwconv_tiled.hip): dw[c][t] += sum_b slab[b][cblk][t*cb+cc]; dbias from row 9
+__device__ __forceinline__ void fold_depthwise(const float* ws, int nblk, int ncb, int cbw, int C, int csrc, float* dw,
+                                               float* dbias, int cblk, int split, int rsplit) {
+    const int per = (nblk + rsplit - 1) / rsplit;
+    const int b0 = split * per, b1 = min(nblk, b0 + per);
+    if (b0 >= b1) return;
+    for (int i = threadIdx.x; i < 10 * cbw; i += 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += ws[((long)b * ncb + cblk) * 10 * cbw + i];
+        const int tp = i / cbw, c = cblk * cbw + (i - tp * cbw);
+        if (c >= csrc || c >= C) continue;
+        if (tp < 9) atomicAdd(dw + c * 9 + tp, s);
+        else if (dbias) atomicAdd(dbias + c, s);
+    }
+}
+
+// the deferred folds of a whole backward pass, FOLD_CHUNK descriptors per launch (kernel arguments: a captured
+// hipGraph keeps them by value); a workgroup finds its descriptor by binary search over the block prefix
+constexpr int FOLD_CHUNK = 32;
+struct FoldChunk { FoldDesc d[FOLD_CHUNK]; int n; };
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(FoldChunk ch) {
+    int lo = 0, hi = ch.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ch.d[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const FoldDesc& d = ch.d[lo];
+    const int lb = blockIdx.x - d.first_block;
+    if (d.kind == 0) {
+        const int slabf = d.tn * d.tk * 1024 + d.tn * 32;
+        const int nbx = (slabf + 255) / 256;
+        WgReduce q{d.ws, d.dw, d.dbias, d.kmap, d.gx, d.gy, d.taps, d.groups_k, d.tn, d.tk, d.N, d.cin, d.ksrc, d.out_mode, d.rsplit};
+        fold_fragments(q, lb % nbx, nbx, (lb / nbx) % d.gy, lb / (nbx * d.gy));
+    } else {
+        fold_depthwise(d.ws, d.gx, d.gy, d.tk, d.N, d.ksrc, d.dw, d.dbias, lb % d.gy, lb / d.gy, d.rsplit);
+    }
+}
+
+// thread-local deferral state (one Python thread drives a GPU; capture happens on the same thread)
+struct DeferState {
+    bool active = false, from_arena = false;
+    float* arena = nullptr; long arena_floats = 0, used = 0, peak = 0;
+    std::vector<FoldDesc> tab;
+};
+thread_local DeferState g_defer;
+constexpr long DEFER_MIN_FLOATS = 16L << 20;       // below this much arena left, fall back to the immediate fold
 
 static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipStream_t s) {
     const int slabf = tn * tk * 1024 + tn * 32;
@@ -271,6 +324,10 @@ static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipS
     if (rsplit > 64) rsplit = 64;
     if (rsplit > gx) rsplit = gx;
     if (rsplit < 1) rsplit = 1;
+    if (g_defer.active && g_defer.from_arena) {
+        FoldDesc d{p.ws, p.dw, p.dbias, p.kmap, 0, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode, 0, 0, 0};
+        if (defer_push(d, (long)gx * gy * p.taps * slabf)) return ISA_OK;
+    }
     WgReduce q{p.ws, p.dw, p.dbias, p.kmap, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode, rsplit};
     dim3 grid(cdiv(slabf, 256), gy, p.taps * rsplit);
     hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, s, q);
@@ -472,6 +529,7 @@ int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (nchunks + 3) / 4;
     long cap = (256L * 2) / ((long)gy * p.taps);
+    p.ws = defer_ws(p.ws, &p.ws_floats);
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
     if (ws_cap < 1) return ISA_EINVAL;                    // workspace too small for even one slab set
     if (cap > ws_cap) cap = ws_cap;
@@ -497,6 +555,7 @@ int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (p.nchunks + 3) / 4;
     long cap = (256L * 2) / ((long)gy * p.taps);
+    p.ws = defer_ws(p.ws, &p.ws_floats);
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
     if (ws_cap < 1) return ISA_EINVAL;
     if (cap > ws_cap) cap = ws_cap;
@@ -611,4 +670,58 @@ int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn,
     p.ws = ws; p.dw = dw; p.dbias = dbias; p.kmap = nullptr; p.taps = taps; p.groups_k = 1; p.N = N; p.cin = cin;
     p.ksrc = cin; p.out_mode = ISA_OUT_PLAIN;
     return launch_reduce(p, gx, 1, tn, tk, s);
+}
+
+// ---- deferred folds ---------------------------------------------------------------------------------
+float* defer_ws(float* ws, long* ws_floats) {
+    DeferState& d = g_defer;
+    d.from_arena = false;
+    if (!d.active || d.arena_floats - d.used < DEFER_MIN_FLOATS) return ws;
+    d.from_arena = true;
+    *ws_floats = d.arena_floats - d.used;
+    return d.arena + d.used;
+}
+
+bool defer_push(FoldDesc f, long used_floats) {
+    DeferState& d = g_defer;
+    if (!d.active || !d.from_arena || f.ws != d.arena + d.used || used_floats > d.arena_floats - d.used) return false;
+    d.from_arena = false;
+    // ~32 slabs per adder (independent coalesced loads); the whole backward pass supplies the parallelism
+    int rsplit = (f.gx + 31) / 32;
+    if (rsplit > 64) rsplit = 64;
+    if (rsplit < 1) rsplit = 1;
+    f.rsplit = rsplit;
+    if (f.kind == 0) f.blocks = cdiv(f.tn * f.tk * 1024 + f.tn * 32, 256) * f.gy * f.taps * rsplit;
+    else f.blocks = f.gy * rsplit;
+    d.tab.push_back(f);
+    d.used += (used_floats + 63) & ~63L;
+    if (d.used > d.peak) d.peak = d.used;
+    return true;
+}
+
+extern "C" int isa_wgrad_defer_begin(float* arena, int64_t arena_floats) {
+    if (!arena || arena_floats < DEFER_MIN_FLOATS || ((uintptr_t)arena & 255)) return ISA_EINVAL;
+    DeferState& d = g_defer;
+    d.active = true; d.from_arena = false; d.arena = arena; d.arena_floats = arena_floats; d.used = 0;
+    d.tab.clear();
+    return ISA_OK;
+}
+
+extern "C" int isa_wgrad_defer_flush(void* stream, int32_t* n_folds, int64_t* arena_used) {
+    DeferState& d = g_defer;
+    if (!d.active) return ISA_EINVAL;
+    d.active = false;
+    if (n_folds) *n_folds = (int32_t)d.tab.size();
+    if (arena_used) *arena_used = d.used;
+    for (size_t i0 = 0; i0 < d.tab.size(); i0 += FOLD_CHUNK) {
+        FoldChunk ch;
+        ch.n = (int)(d.tab.size() - i0 < (size_t)FOLD_CHUNK ? d.tab.size() - i0 : FOLD_CHUNK);
+        int blocks = 0;
+        for (int i = 0; i < ch.n; ++i) { ch.d[i] = d.tab[i0 + i]; ch.d[i].first_block = blocks; blocks += ch.d[i].blocks; }
+        for (int i = ch.n; i < FOLD_CHUNK; ++i) ch.d[i] = FoldDesc{};
+        if (blocks > 0) hipLaunchKernelGGL(wgrad_fold_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), ch);
+        if (launch_status() != ISA_OK) { d.tab.clear(); return ISA_ELAUNCH; }
+    }
+    d.tab.clear();
+    return ISA_OK;
 }

@@ -428,6 +428,7 @@ int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, hipStream_t s) {
     long gx = (256L * 2) / ncb;          // 2 resident workgroups per CU
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
+    p.ws = defer_ws(p.ws, &ws_floats);
     const long ws_cap = ws_floats / (10L * CB * ncb);
     if (ws_cap < 1) return ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
@@ -436,6 +437,9 @@ int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, hipStream_t s) {
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
     else if (has_pro) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ACT_RT>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((dw2_wgrad_kernel<T, false, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
+    if (launch_status() != ISA_OK) return ISA_ELAUNCH;
+    if (defer_push(FoldDesc{p.ws, (float*)p.y, (float*)p.bias, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
+                   gx * ncb * 10L * CB)) return ISA_OK;
     hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, (float*)p.y, (float*)p.bias);
     return launch_status();
 }
@@ -790,6 +794,7 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     long gx = (256L * per_cu) / ncb;
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
+    p.ws = defer_ws(p.ws, &ws_floats);
     const long ws_cap = ws_floats / (10L * CB * ncb);
     if (ws_cap < 1) return ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
@@ -800,6 +805,8 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     else if (xmode == 1) rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 1>(p, grid, s) : launch_fused_inst<T, ACT_RT, 1>(p, grid, s);
     else rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 2>(p, grid, s) : launch_fused_inst<T, ACT_RT, 2>(p, grid, s);
     if (rc != ISA_OK) return rc;
+    if (defer_push(FoldDesc{p.ws, p.dw, nullptr, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
+                   gx * ncb * 10L * CB)) return ISA_OK;
     hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, p.dw, (float*)nullptr);
     return launch_status();
 }

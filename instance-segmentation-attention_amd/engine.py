@@ -393,6 +393,12 @@ class Engine:
         self.side_stream = None
         self.ws_side = None
         self._side_used = False
+        # Deferred weight-gradient folds (isa_wgrad_defer_begin/_flush): the ~270 second-stage fold launches of a
+        # backward pass collapse into ~9 at its end; partial slabs live in their own arena until then.
+        # ISA_DEFER_FOLD=0 restores the immediate folds (A/B measurements).
+        self.defer_fold = os.environ.get("ISA_DEFER_FOLD", "1") != "0"
+        self.fold_arena = None
+        self.fold_stats = (0, 0)       # (folds, arena floats) of the last backward pass
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool):
@@ -844,8 +850,21 @@ class Engine:
         return torch.cuda.stream(self.side_stream)
 
     def backward(self):
-        for fn in reversed(self.tape):
-            fn()
+        if self.defer_fold:
+            if self.fold_arena is None:
+                self.fold_arena = torch.empty(int(os.environ.get("ISA_FOLD_ARENA_MB", "2048")) << 18,
+                                              dtype=torch.float32, device=self.device)
+            L.check(self.lib.isa_wgrad_defer_begin(L.ptr(self.fold_arena), self.fold_arena.numel()),
+                    "isa_wgrad_defer_begin")
+        try:
+            for fn in reversed(self.tape):
+                fn()
+        finally:
+            if self.defer_fold:
+                nf, used = C.c_int32(0), C.c_int64(0)
+                L.check(self.lib.isa_wgrad_defer_flush(self.st(), C.byref(nf), C.byref(used)),
+                        "isa_wgrad_defer_flush")
+                self.fold_stats = (nf.value, used.value)
         self.tape = []
         if self._side_used:                          # join before anything (optimizer, all-reduce) reads the gradients
             torch.cuda.current_stream().wait_stream(self.side_stream)

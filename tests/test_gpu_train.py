@@ -230,3 +230,25 @@ def test_training_points_are_sampled_from_alpha():
             greedy_hits += int((alpha.argmax(1) == s_t).sum())
             total += s_t.numel()
     assert greedy_hits < total, "sampling degenerated to argmax"
+
+
+def test_deferred_weight_gradient_folds_match_immediate_folds():
+    """isa_wgrad_defer_begin/_flush: the same slabs folded at the end of the backward pass instead of after each
+    layer.  Only the order of the fp32 atomic adds differs."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_f64.npz"))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.bfloat16)
+    E = m.engine
+    grads = {}
+    for mode in (False, True):
+        E.defer_fold = mode
+        tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+        torch.cuda.synchronize()
+        grads[mode] = m.store.grad.clone()
+    folds, used = E.fold_stats
+    assert folds > 100, "the backward pass should have recorded its folds (%d)" % folds
+    assert 0 < used <= E.fold_arena.numel()
+    a, b = grads[False].double(), grads[True].double()
+    assert torch.isfinite(b).all()
+    rel = float((a - b).norm() / a.norm())
+    assert rel < 1e-5, rel
