@@ -860,12 +860,12 @@ class Engine:
             for fn in reversed(self.tape):
                 fn()
         finally:
+            if self._side_used:                      # join before the folds / optimizer / all-reduce read slabs and gradients
+                torch.cuda.current_stream().wait_stream(self.side_stream)
+                self._side_used = False
             if self.defer_fold:
                 nf, used = C.c_int32(0), C.c_int64(0)
                 L.check(self.lib.isa_wgrad_defer_flush(self.st(), C.byref(nf), C.byref(used)),
                         "isa_wgrad_defer_flush")
                 self.fold_stats = (nf.value, used.value)
         self.tape = []
-        if self._side_used:                          # join before anything (optimizer, all-reduce) reads the gradients
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-            self._side_used = False
