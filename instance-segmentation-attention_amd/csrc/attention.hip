@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void gate_kernel(View up, View pred, View out,
 template <typename T>
 __global__ __launch_bounds__(256) void mask_loss_sums_kernel(View pred, const float* target, const int64_t* onehot,
                                                              float* sums) {
-    __shared__ float sh[16];
+    __shared__ float sh[32];
     const int b = blockIdx.y;
     const long L = (long)pred.h * pred.w;
     float a[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -419,11 +419,7 @@ __global__ __launch_bounds__(256) void mask_loss_sums_kernel(View pred, const fl
         a[4] += lse - (t > 0.5f ? l1 : l0);
         a[5] += p1 * p1; a[6] += 1.f;
     }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const float s = block_sum(a[k], sh);
-        if (threadIdx.x == 0 && s != 0.f) atomicAdd(sums + 8 * b + k, s);
-    }
+    block_sums_atomic<7>(a, sh, sums + 8 * b);
 }
 
 }  // namespace

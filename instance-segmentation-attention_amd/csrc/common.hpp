@@ -176,6 +176,27 @@ __device__ __forceinline__ float fold_stride(float v, int cg, int lane) {
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }
 
+// K workgroup-wide sums added to dst[0..K) with ONE wave-wide atomic request per workgroup (sh: >= (blockDim/64)*K
+// floats).  K single-lane atomicAdds per workgroup are K memory-side requests on the same line: 2048 workgroups x 4
+// of them made a 15 us reduction take 116 us.
+template <int K>
+__device__ __forceinline__ void block_sums_atomic(float (&a)[K], float* sh, float* dst) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = wave_sum(a[k]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sh[wave * K + k] = a[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        float r = 0.f;
+        for (int w = 0; w < nw; ++w) r += sh[w * K + threadIdx.x];
+        if (r != 0.f) atomicAdd(dst + threadIdx.x, r);
+    }
+}
+
 // ---- deferred slab folds (isa_wgrad_defer_begin / isa_wgrad_defer_flush; defined in conv_wgrad.hip) ----
 // Weight gradients are leaves of the backward graph: nothing reads dW before the optimizer.  While deferral is
 // active the weight-gradient launchers take their partial-slab region from a step arena (defer_ws) and record the

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void maskbn_bwd_reduce_kernel(View e, const fl
         const float d = st<T>::ld(reinterpret_cast<const T*>(e.data) + pix * e.ld) - mu;
         a0 += g * ww; a1 += g * ww * d; a2 += g * d * inv; a3 += g;
     }
-    a0 = block_sum(a0, sh); a1 = block_sum(a1, sh); a2 = block_sum(a2, sh); a3 = block_sum(a3, sh);
-    if (threadIdx.x == 0) { atomicAdd(red, a0); atomicAdd(red + 1, a1); atomicAdd(red + 2, a2); atomicAdd(red + 3, a3); }
+    float a[4] = {a0, a1, a2, a3};
+    block_sums_atomic<4>(a, sh, red);
 }
 // tiny: k[0]=dvar, k[1]=dmean; param grads
 __global__ void maskbn_bwd_finalize_kernel(const float* red, const float* am, const float* mean_var, int n, float eps,
@@ -693,8 +693,8 @@ extern "C" int isa_maskbn_bwd(const isa_tensor* e, const float* sem, const float
     const int grid = grid_cap(cdiv((long)e->n * e->h * e->w, 256));
     hipStream_t s = as_stream(stream);
     DISPATCH_T(e->dtype,
-        hipLaunchKernelGGL(maskbn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, mkview(e), sem, dmerge, mean_var, w, eps, red4),
-        hipLaunchKernelGGL(maskbn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, mkview(e), sem, dmerge, mean_var, w, eps, red4));
+        hipLaunchKernelGGL(maskbn_bwd_reduce_kernel<bf16_t>, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, mkview(e), sem, dmerge, mean_var, w, eps, red4),
+        hipLaunchKernelGGL(maskbn_bwd_reduce_kernel<float>, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, mkview(e), sem, dmerge, mean_var, w, eps, red4));
     hipLaunchKernelGGL(maskbn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, red4, am, mean_var, e->n, eps, train, k2, dw, db);
     DISPATCH_T(e->dtype,
         hipLaunchKernelGGL(maskbn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, mkview(e), sem, dmerge, mean_var, w, eps, am, k2, train, mkview(de), accumulate),
