@@ -138,6 +138,9 @@ def main():
             gx_.copy_(x); gsem_.copy_(sem); gins_.copy_(ins)
             x, sem, ins = gx_, gsem_, gins_
             sync_all()
+    if workload == "train_step" and model.engine.fold_stats[0]:
+        log("weight-gradient folds postponed to the end of the backward pass: %d per step, %.0f MB of slab arena"
+            % (model.engine.fold_stats[0], model.engine.fold_stats[1] * 4 / 1e6))
     log("workload=%s dtype=%s world=%d: warmup" % (workload, args.dtype, world))
     for _ in range(args.warmup):
         step()
