@@ -307,6 +307,14 @@ int isa_point_query(const float* q, const isa_tensor* enc, float* out, void* str
  * channels are written as zero).  out = ([rgb, lab, hsv, yuv, ycbcr, hed, yiq] - 0.5) * 2.                     */
 int isa_image_ex(const uint8_t* rgb, const isa_tensor* out, void* stream);
 
+/* ---- target expansion (the tail of the collate function): AlignCollate.__call__,
+ * code/lib/dataset.py:349-379, widens the uint8 instance planes to int64 [bs,K,h,w] and builds the int64 semantic
+ * one-hot [bs,2,h,w] on the host.  Here: ins uint8 [n,h,w,k] (the array `instance_annotations` of :349-351 before
+ * the cast) -> ins_out int64 [n,k,h,w], values preserved; sem uint8 [n,h,w] (may be NULL) -> sem_out int64 [n,2,h,w],
+ * channel c = (sem == c) as np.eye(2)[sem] (:356-361; a value > 1 is an IndexError there and all-zero here).  k <= 252. */
+int isa_collate_targets(const uint8_t* ins, const uint8_t* sem, int32_t n, int32_t h, int32_t w, int32_t k,
+                        int64_t* ins_out, int64_t* sem_out, void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);

@@ -40,8 +40,12 @@ def synth_batch(batch, height, width, seed=0, max_objects=32, kmin=3, kmax=8):
 class SyntheticLoader(object):
     """Iterable of `n_batches` collated minibatches, re-seeded per epoch like a shuffling DataLoader."""
 
-    def __init__(self, n_batches, batch_size, height=256, width=256, seed=0):
+    def __init__(self, n_batches, batch_size, height=256, width=256, seed=0, compact=False):
+        """compact=True yields the targets as the reference's collate function holds them before its last five lines
+        (dataset.py:349-379): sem uint8 [B,H,W], ins uint8 [B,H,W,32]; the model expands them on the device
+        (isa_collate_targets) - 8x less host-to-device traffic per step."""
         self.n, self.bs, self.h, self.w, self.seed, self.epoch = n_batches, batch_size, height, width, seed, 0
+        self.compact = compact
 
     def __len__(self):
         return self.n
@@ -49,4 +53,7 @@ class SyntheticLoader(object):
     def __iter__(self):
         self.epoch += 1
         for i in range(self.n):
-            yield synth_batch(self.bs, self.h, self.w, seed=self.seed + 1000 * self.epoch + i)
+            x, sem, ins, n = synth_batch(self.bs, self.h, self.w, seed=self.seed + 1000 * self.epoch + i)
+            if self.compact:
+                sem, ins = sem[:, 1].contiguous().to(torch.uint8), ins.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+            yield x, sem, ins, n

@@ -183,6 +183,21 @@ class Network:
             return self.image_ex(x)
         return self.to_nhwc(x.to(device=self.E.device, dtype=torch.float32))
 
+    def collate_targets(self, sem: torch.Tensor, ins: torch.Tensor):
+        """Targets as the reference's collate function leaves them before its last five lines (dataset.py:349-379):
+        ins uint8 [n,h,w,K] instance planes, sem uint8 [n,h,w] -> (sem one-hot int64 [n,2,h,w], ins int64 [n,K,h,w])
+        on the device (isa_collate_targets).  8.6x less PCIe traffic than shipping the int64 tensors."""
+        E = self.E
+        assert ins.dtype == torch.uint8 and ins.dim() == 4 and sem.dtype == torch.uint8 and sem.dim() == 3
+        n, h, w, k = ins.shape
+        assert tuple(sem.shape) == (n, h, w)
+        ins, sem = ins.to(E.device).contiguous(), sem.to(E.device).contiguous()
+        ins_out = E.arena.alloc((n, k, h, w), torch.int64)
+        sem_out = E.arena.alloc((n, 2, h, w), torch.int64)
+        L.check(E.lib.isa_collate_targets(L.ptr(ins), L.ptr(sem), n, h, w, k, L.ptr(ins_out), L.ptr(sem_out), E.st()),
+                "isa_collate_targets")
+        return sem_out, ins_out
+
     def to_nchw(self, a: Act) -> torch.Tensor:
         E = self.E
         out = torch.empty((a.n, a.c, a.h, a.w), dtype=torch.float32, device=a.buf.device)

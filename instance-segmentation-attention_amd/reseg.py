@@ -179,7 +179,7 @@ class ReSeg(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, training, *_input, selected_idx=None, injected_s_t=None, capture=None):
         """reseg.py:106-130.  (x) -> (sem_out, sem_argmax);  (x, sem_onehot[B,2,H,W] i64,
-        ins[B,32,H,W] i64, N[B,1]) -> (sem_out, sem_argmax, ins_cost, criterion, ins_ce_loss,
+        ins[B,32,H,W] i64, N[B,1]) [or the compact uint8 pair sem[B,H,W], ins[B,H,W,32]: expanded on device] -> (sem_out, sem_argmax, ins_cost, criterion, ins_ce_loss,
         ins_dice_loss).  BatchNorm mode follows .train()/.eval() like the reference modules; the
         `training` flag drives sampling, F.dropout2d and the loss branch (attenet2.py:377-399).
         `selected_idx` / `injected_s_t` inject the reference's host RNG choices (random.shuffle,
@@ -202,6 +202,8 @@ class ReSeg(nn.Module):
         if getattr(self, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         self._weights_dirty = False
+        if has_gt and ins_seg_target.dtype == torch.uint8:      # compact targets: net.collate_targets (dataset.py:349-379)
+            sem_seg_target, ins_seg_target = net.collate_targets(sem_seg_target, ins_seg_target)
         xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
         sem = net.sem_head(x_dec)

@@ -41,6 +41,8 @@ class Trainer:
         if getattr(m, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         m._weights_dirty = False
+        if ins.dtype == torch.uint8:         # compact targets (uint8 planes [B,H,W,K] + uint8 map [B,H,W]): expand on device
+            sem, ins = net.collate_targets(sem, ins)
         xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
         sem_a = net.sem_head(x_dec)
@@ -102,7 +104,7 @@ class Trainer:
                 random.shuffle(order)
                 selected_idx.append(order)
         key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
-               m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8)
+               m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8, ins.dtype == torch.uint8)
         slot = self._graphs.get(key)
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")

@@ -26,6 +26,8 @@ parser.add_argument('--nworkers', type=int, default=2, help='accepted for compat
 parser.add_argument('--dataset', type=str, default='CVPPP', help='Name of the dataset which is "CVPPP"')
 parser.add_argument('--iters-per-epoch', type=int, default=8)
 parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+parser.add_argument('--compact-targets', action='store_true',
+                    help='loader yields uint8 targets (sem [B,H,W], ins [B,H,W,32]); expanded on the device')
 parser.add_argument('--out', default=os.path.join(ROOT, 'models', 'CVPPP', 'run'))
 opt = parser.parse_args()
 assert opt.dataset in ['CVPPP', ]
@@ -34,7 +36,8 @@ SEED = 23                                                     # training_setting
 random.seed(SEED); np.random.seed(SEED); torch.manual_seed(SEED)
 model = Model(opt.dataset, 'ReSeg', 2, 32, use_instance_segmentation=True, load_model_path=opt.model, usegpu=True,
               dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32)
-train_loader = SyntheticLoader(opt.iters_per_epoch, opt.batchsize, 256, 256, seed=SEED)
-test_loader = SyntheticLoader(max(1, opt.iters_per_epoch // 4), opt.batchsize, 256, 256, seed=SEED + 7)
+train_loader = SyntheticLoader(opt.iters_per_epoch, opt.batchsize, 256, 256, seed=SEED, compact=opt.compact_targets)
+test_loader = SyntheticLoader(max(1, opt.iters_per_epoch // 4), opt.batchsize, 256, 256, seed=SEED + 7,
+                              compact=opt.compact_targets)
 model.fit('Multi', 0.5, 1.5, 2, 1.0, 0.001, 10.0, 0.5, 25, False, 'Adadelta', True, opt.nepochs, None,
           train_loader, test_loader, opt.out, opt.debug)
