@@ -315,6 +315,15 @@ int isa_image_ex(const uint8_t* rgb, const isa_tensor* out, void* stream);
 int isa_collate_targets(const uint8_t* ins, const uint8_t* sem, int32_t n, int32_t h, int32_t w, int32_t k,
                         int64_t* ins_out, int64_t* sem_out, void* stream);
 
+/* ---- exact augmentations: the index-permuting part of AlignCollate.__preprocess,
+ * code/lib/dataset.py:185-233 - horizontal flip, vertical flip, transpose, rotation by k*90 degrees (preprocess.py:171,
+ * 218,286,323; PIL FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM / TRANSPOSE / rotate(expand=True)), in the reference's order.
+ * src, dst: uint8 [n,s,s,c] (square images; c = 3 image, 1 semantic map, 32 instance planes), out of place.
+ * ops_dev: int32 [n] on the device, per image: bit0 hflip, bit1 vflip, bit2 transpose, bits 3-4 = quarter turns
+ * counter-clockwise (rot_angle / 90).  The random draws stay on the host as in the reference (:186,198,210,222). */
+int isa_d4_augment(const uint8_t* src, uint8_t* dst, int32_t n, int32_t s, int32_t c, const int32_t* ops_dev,
+                   void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);

@@ -57,3 +57,23 @@ class SyntheticLoader(object):
             if self.compact:
                 sem, ins = sem[:, 1].contiguous().to(torch.uint8), ins.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
             yield x, sem, ins, n
+
+
+def d4_augment(tensors, ops, device="cuda"):
+    """The exact augmentations of the reference's collate function (dataset.py:185-233: horizontal / vertical flip,
+    transpose, 90x rotation) on the device, one shared op code per image for all of `tensors` (uint8 [n,s,s,c] or
+    [n,s,s]: RGB image, semantic map, instance planes).  ops: per-image codes, bit0 hflip, bit1 vflip, bit2 transpose,
+    bits 3-4 = rot_angle // 90; the random draws stay on the host in the reference's call order (three
+    random.random() < 0.5, one np.random.choice([0, 90, 180, 270]) per image).  Returns new device tensors."""
+    from . import lib as L
+    ops_dev = torch.as_tensor(list(ops), dtype=torch.int32).to(device)
+    out = []
+    for t in tensors:
+        assert t.dtype == torch.uint8 and t.dim() in (3, 4) and t.shape[1] == t.shape[2], "uint8 [n,s,s(,c)]"
+        src = t.to(device).contiguous()
+        dst = torch.empty_like(src)
+        c = 1 if t.dim() == 3 else t.shape[3]
+        L.check(L.lib().isa_d4_augment(L.ptr(src), L.ptr(dst), src.shape[0], src.shape[1], c, L.ptr(ops_dev),
+                                       L.stream_ptr()), "isa_d4_augment")
+        out.append(dst)
+    return out

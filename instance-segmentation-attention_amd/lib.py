@@ -58,6 +58,7 @@ SIGNATURES = {
     "isa_conv1x1_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, P_T, I32, P_T, VP, I64, VP],
     "isa_wgrad_defer_begin": [VP, I64],
     "isa_wgrad_defer_flush": [VP, VP, VP],
+    "isa_d4_augment": [VP, VP, I32, I32, I32, VP, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],
     "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
