@@ -77,3 +77,40 @@ def d4_augment(tensors, ops, device="cuda"):
                                        L.stream_ptr()), "isa_d4_augment")
         out.append(dst)
     return out
+
+
+class DevicePrefetcher(object):
+    """Wraps an iterable of collated host batches (x, sem, ins, n): batch i+1 travels to the device on its own HIP
+    stream while step i computes, so the host-to-device time of the reference's hand-over (373 MB per step at bs=16:
+    fp32 input, int64 targets) leaves the critical path.  Host tensors are pinned once per batch; `n` stays on the
+    host (the model reads it there).  Yields device tensors that the consumer's stream may use immediately."""
+
+    def __init__(self, loader, device="cuda"):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, batch):
+        x, sem, ins, n = batch
+        with torch.cuda.stream(self.stream):
+            dev = [t.pin_memory().to(self.device, non_blocking=True) if not t.is_cuda else t for t in (x, sem, ins)]
+        return dev[0], dev[1], dev[2], n
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._upload(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)     # batch i has landed
+            for t in cur[:3]:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            try:
+                nxt = self._upload(next(it))                                     # batch i+1 starts moving now
+            except StopIteration:
+                nxt = None
+            yield cur

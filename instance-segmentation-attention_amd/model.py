@@ -88,6 +88,9 @@ class Model(object):
         tlog.write('Epoch,Cost\n'); vlog.write('Epoch,Cost\n')
         self.__define_optimizer(learning_rate, weight_decay, lr_drop_factor, lr_drop_patience, clip_grad_norm, optimizer)
         best_val_cost = np.inf
+        if os.environ.get('ISA_PREFETCH', '1') != '0':      # batch i+1 uploads on a side stream while step i runs
+            from .data import DevicePrefetcher
+            train_loader, test_loader = DevicePrefetcher(train_loader), DevicePrefetcher(test_loader)
         for epoch in range(n_epochs):
             tr = [self.__minibatch(b, 'training') for b in train_loader]
             va = [self.__minibatch(b, 'test') for b in test_loader]

@@ -49,7 +49,38 @@ def run(label, hx, hsem, hins):
     torch.cuda.empty_cache()
 
 
+def run_prefetched(label, hx, hsem, hins):
+    from isa_amd.data import DevicePrefetcher
+    m = ReSeg(2, True, dtype=torch.bfloat16)
+    m.reset_parameters(seed=23)
+    m.train()
+    tr = Trainer(m)
+    hx, hsem, hins = hx.pin_memory(), hsem.pin_memory(), hins.pin_memory()
+
+    class Loader(object):
+        def __init__(self, k): self.k = k
+        def __len__(self): return self.k
+        def __iter__(self):
+            for _ in range(self.k):
+                yield hx, hsem, hins, n
+    for b in DevicePrefetcher(Loader(5)):
+        tr.train_step_graphed(b[0], b[1], b[2], b[3], selected_idx=sel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in DevicePrefetcher(Loader(K)):
+        tr.train_step_graphed(b[0], b[1], b[2], b[3], selected_idx=sel)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    print("%-58s %7s                     %6.2f ms/step  %6.1f images/s" % (label, "", dt * 1e3, B / dt))
+    del m, tr
+    torch.cuda.empty_cache()
+
+
 print("train step 256x256 bs=%d bf16, hipGraph replay, host batch copied in every step (serial copy + step)" % B)
 run("reference hand-over (x fp32, sem/ins int64)", x, sem, ins)
 run("compact hand-over (rgb/sem/ins uint8, expansion on device)", rgb, sem[:, 1].contiguous().to(torch.uint8),
     ins.permute(0, 2, 3, 1).contiguous().to(torch.uint8))
+print("the same with isa_amd.data.DevicePrefetcher (batch i+1 uploads on a side stream during step i)")
+run_prefetched("reference hand-over, prefetched", x, sem, ins)
+run_prefetched("compact hand-over, prefetched", rgb, sem[:, 1].contiguous().to(torch.uint8),
+               ins.permute(0, 2, 3, 1).contiguous().to(torch.uint8))

@@ -35,3 +35,20 @@ def test_fit_and_predict(tmp_path):
     assert prob.shape == (2, 2, 64, 64) and torch.allclose(prob.sum(1), torch.ones(2, 64, 64), atol=1e-5)
     with pytest.raises(AssertionError):
         m2.predict(x[0])                      # 4-D input check (model.py:468)
+
+
+def test_device_prefetcher_yields_the_same_batches_in_order():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import isa_amd  # noqa: F401
+    from isa_amd.data import DevicePrefetcher, SyntheticLoader
+    host = list(SyntheticLoader(3, 2, 32, 32, seed=4, compact=True))
+    loader = SyntheticLoader(3, 2, 32, 32, seed=4, compact=True)
+    got = list(DevicePrefetcher(loader))
+    torch.cuda.synchronize()
+    assert len(got) == 3 == len(DevicePrefetcher(loader))
+    for h, d in zip(host, got):
+        for a, b in zip(h[:3], d[:3]):
+            assert b.is_cuda and torch.equal(a, b.cpu())
+        assert torch.equal(h[3], d[3]) and not d[3].is_cuda
+    assert list(DevicePrefetcher([])) == []
