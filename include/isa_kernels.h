@@ -324,6 +324,13 @@ int isa_collate_targets(const uint8_t* ins, const uint8_t* sem, int32_t n, int32
 int isa_d4_augment(const uint8_t* src, uint8_t* dst, int32_t n, int32_t s, int32_t c, const int32_t* ops_dev,
                    void* stream);
 
+/* Nearest-neighbour resize of annotation planes: the `ann_resizer` of AlignCollate
+ * (code/lib/dataset.py:162,168,293-320 -> utils.py:26-27 -> PIL Image.resize(NEAREST), once per instance plane and
+ * semantic map on the host).  src uint8 [n,h0,w0,c] -> dst uint8 [n,h,w,c], out of place; source row/column tables
+ * follow Pillow's ImagingScaleAffine exactly (half-step start, step accumulated in double), h, w <= 768.          */
+int isa_resize_nearest_u8(const uint8_t* src, int32_t n, int32_t h0, int32_t w0, int32_t c, uint8_t* dst,
+                          int32_t h, int32_t w, void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "isa_wgrad_defer_begin": [VP, I64],
     "isa_wgrad_defer_flush": [VP, VP, VP],
     "isa_d4_augment": [VP, VP, I32, I32, I32, VP, VP],
+    "isa_resize_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],
     "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
