@@ -114,3 +114,27 @@ class DevicePrefetcher(object):
             except StopIteration:
                 nxt = None
             yield cur
+
+
+def device_collate_targets(planes, sem, ops=None, size=256, device="cuda"):
+    """The annotation side of the reference's collate function on the device, in its order (dataset.py:185-233 exact
+    augmentations at the source resolution, :293-320 nearest resize, :349-379 int64 planes + one-hot):
+    planes uint8 [n,h0,w0,K] (zero planes already appended up to K = 32, :305-311), sem uint8 [n,h0,w0], ops = per-image
+    D4 op codes or None.  Square sources are required when an op transposes.  Returns (sem_onehot int64 [n,2,size,size],
+    ins int64 [n,K,size,size]) on the device; three launches instead of ~70 PIL calls per image."""
+    from . import lib as L
+    planes, sem = planes.to(device).contiguous(), sem.to(device).contiguous()
+    n, h0, w0, k = planes.shape
+    sem4 = sem.reshape(n, h0, w0, 1)
+    if ops is not None:
+        planes, sem4 = d4_augment([planes, sem4], ops, device)
+    st = L.stream_ptr()
+    p2 = torch.empty((n, size, size, k), dtype=torch.uint8, device=device)
+    s2 = torch.empty((n, size, size, 1), dtype=torch.uint8, device=device)
+    L.check(L.lib().isa_resize_nearest_u8(L.ptr(planes), n, h0, w0, k, L.ptr(p2), size, size, st), "isa_resize_nearest_u8")
+    L.check(L.lib().isa_resize_nearest_u8(L.ptr(sem4), n, h0, w0, 1, L.ptr(s2), size, size, st), "isa_resize_nearest_u8")
+    ins_out = torch.empty((n, k, size, size), dtype=torch.int64, device=device)
+    sem_out = torch.empty((n, 2, size, size), dtype=torch.int64, device=device)
+    L.check(L.lib().isa_collate_targets(L.ptr(p2), L.ptr(s2), n, size, size, k, L.ptr(ins_out), L.ptr(sem_out), st),
+            "isa_collate_targets")
+    return sem_out, ins_out

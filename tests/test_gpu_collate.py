@@ -100,3 +100,29 @@ def test_trainer_accepts_compact_targets():
     out = tr.train_step_graphed(x, sem_u8, ins_u8, n, selected_idx=sel)     # capture + replay
     torch.cuda.synchronize()
     assert torch.isfinite(out["sem"]).all()
+
+
+def test_device_annotation_pipeline_matches_the_oracle_chain():
+    """augment (source resolution) -> nearest resize -> int64 planes / one-hot, the order of dataset.py:185-379."""
+    L = _lib()
+    import augment_ref as A
+    import resize_ref as Z
+    from isa_amd.data import device_collate_targets
+    rng = np.random.default_rng(9)
+    n, s0, k, size = 3, 90, 32, 64
+    planes = (rng.random((n, s0, s0, k)) < 0.3).astype(np.uint8)
+    sem = (planes.sum(-1) > 0).astype(np.uint8)
+    ops = [13, 0, 30]
+    sem_oh, ins = device_collate_targets(torch.from_numpy(planes), torch.from_numpy(sem), ops, size)
+    p_ref = Z.resize_nearest(A.d4_batch(planes, ops), size, size)
+    s_ref = Z.resize_nearest(A.d4_batch(sem[..., None], ops), size, size)[..., 0]
+    want_oh, want_ins = R.collate_targets(p_ref, s_ref)
+    np.testing.assert_array_equal(ins.cpu().numpy(), want_ins)
+    np.testing.assert_array_equal(sem_oh.cpu().numpy(), want_oh)
+    # non-square sources without ops (validation mode of the reference: no augmentation)
+    planes2 = (rng.random((2, 53, 50, k)) < 0.3).astype(np.uint8)
+    sem2 = (planes2.sum(-1) > 0).astype(np.uint8)
+    oh2, ins2 = device_collate_targets(torch.from_numpy(planes2), torch.from_numpy(sem2), None, size)
+    w_oh, w_ins = R.collate_targets(Z.resize_nearest(planes2, size, size), Z.resize_nearest(sem2[..., None], size, size)[..., 0])
+    np.testing.assert_array_equal(ins2.cpu().numpy(), w_ins)
+    np.testing.assert_array_equal(oh2.cpu().numpy(), w_oh)
