@@ -176,7 +176,9 @@ def main():
         E = model.engine
         E.profile = True
         if workload == "train_step":                              # per-launch events need the eager launch loop
-            eager_step()
+            # forward + backward only: this block runs on rank 0 alone, so it must stay collective-free (the update's
+            # all-reduce would wait forever for the other ranks)
+            trainer.forward_backward(x, sem, ins, n, selected_idx=sel)
         elif workload == "infer":
             model(False, x)
         else:

@@ -28,7 +28,7 @@ extern "C" {
 enum { ISA_F32 = 0, ISA_BF16 = 1 };
 enum { ISA_ACT_NONE = 0, ISA_ACT_RELU = 1, ISA_ACT_RELU6 = 2, ISA_ACT_LEAKY = 3, ISA_ACT_TANH = 4 };
 enum { ISA_STAT_REPLICAS = 8 };   /* layout of every per-channel statistics buffer: [8][2*C] */
-enum { ISA_OK = 0, ISA_EINVAL = -1, ISA_EALIGN = -2, ISA_EDTYPE = -3, ISA_ELAUNCH = -4 };
+enum { ISA_OK = 0, ISA_EINVAL = -1, ISA_EALIGN = -2, ISA_EDTYPE = -3, ISA_ELAUNCH = -4, ISA_ENOMEM = -5 };
 
 /* conv_gemm input addressing */
 enum { ISA_IN_1X1 = 0,       /* K = Cin                       (nn.Conv2d k=1)                    */
@@ -54,6 +54,8 @@ typedef struct isa_pro {       /* lazy-input prologue; all pointers may be NULL 
     const float* bscale;       /* [n,c] per-image channel multiplier (Dropout2d mask, SE gate) */
     int32_t      act;          /* ISA_ACT_* applied after the affine, before bscale */
 } isa_pro;
+
+typedef struct isa_slab_arena isa_slab_arena;   /* opaque: deferred weight-gradient folds, see below */
 
 typedef struct isa_pack_entry { /* one parameter tensor to repack (see isa_pack_weights) */
     int64_t src_off;            /* element offset into the fp32 master buffer */
@@ -97,10 +99,12 @@ int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_
  *   += sum_m dy[m,n] * pro(x)[m@tap, kd],  kd -> k through kmap (NULL = identity, -1 = padding).
  * dbias[N] += sum_m dy (optional, not for SHUFFLE2: use isa_colsum).
  * Two launches, no atomics (deterministic): split-M workgroups write partial slabs into `ws`
- * (caller scratch, >= a few MB; the split factor adapts to ws_floats), a reduce kernel folds them. */
+ * (caller scratch, >= a few MB; the split factor adapts to ws_floats), a reduce kernel folds them.
+ * `defer` (optional, all weight-gradient entry points): see isa_slab_arena below. */
 int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                    float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
-                   const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats, void* stream);
+                   const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats, isa_slab_arena* defer,
+                   void* stream);
 /* out[c] += sum over all pixels of x[.,c]  (bias gradients) */
 int isa_colsum(const isa_tensor* x, float* out, void* stream);
 
@@ -114,7 +118,8 @@ int isa_dwconv3x3(const isa_tensor* x, const isa_pro* pro, const void* w, const 
 int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const isa_tensor* dx,
                         int32_t accumulate, void* stream);
 int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
-                        float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, void* stream);
+                        float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, isa_slab_arena* defer,
+                        void* stream);
 
 /* Backward constants of one train-mode BatchNorm2d layer (what torch autograd keeps for
  * native_batch_norm_backward): scale/shift/mean/invstd from isa_bn_finalize, `red` = the
@@ -140,7 +145,7 @@ int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const is
                               const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                               const void* w_flipped, float* dw, int32_t csrc,
                               const isa_tensor* dx, int32_t accumulate, const isa_tensor* addend,
-                              float* ws, int64_t ws_floats, void* stream);
+                              float* ws, int64_t ws_floats, isa_slab_arena* defer, void* stream);
 
 /* The same fusion for a bias-free 1x1 convolution y = W x (W fp32 [N][K], state_dict layout) followed by a
  * train-mode BatchNorm2d (MobileNetDenseASPP.py:105-107,113-114 expand / project; :81-82 InvertedV1):
@@ -152,20 +157,24 @@ int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* y, const is
 int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                             const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                             const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
-                            const isa_tensor* addend, float* ws, int64_t ws_floats, void* stream);
+                            const isa_tensor* addend, float* ws, int64_t ws_floats, isa_slab_arena* defer,
+                            void* stream);
 
 /* ---- deferred weight-gradient folds ------------------------------------------------------------
- * Every weight-gradient entry point above is two-stage: partial slabs in `ws`, then a small fold kernel that adds
- * them into dw/dbias.  Nothing reads a weight gradient before the optimizer (torch autograd gives the same freedom to
- * the reference's loss.backward(), train.py:312-322 -> model.py:204-216), so a backward pass may postpone the folds:
- * between _begin and _flush (same host thread) those entry points ignore their `ws` argument, place their slabs in
- * `arena` one after the other and record the fold; _flush adds every recorded slab set into its dw/dbias with one
- * launch per 32 folds (~190 small launches fewer per training step at the BASELINE configuration).  When less than
- * 64 MB of `arena` is left a call falls back to its own `ws` and folds immediately.  `arena`: fp32, 256-byte
- * aligned, >= 16M floats; must not be reused before the flush's kernels have run.  n_folds / arena_used (optional)
- * report what the pass recorded.                                                                             */
-int isa_wgrad_defer_begin(float* arena, int64_t arena_floats);
-int isa_wgrad_defer_flush(void* stream, int32_t* n_folds, int64_t* arena_used);
+ * Every weight-gradient entry point is two-stage: partial slabs, then a small fold kernel that adds them into
+ * dw/dbias.  Nothing reads a weight gradient before the optimizer (torch autograd gives the same freedom to the
+ * reference's loss.backward(), train.py:312-322 -> model.py:204-216), so a backward pass may postpone the folds.
+ * The state is an explicit handle (no global or thread-local state): an isa_slab_arena wraps a caller-owned fp32
+ * region (256-byte aligned, >= 16M floats).  Weight-gradient entry points that receive the handle (`defer` != NULL)
+ * ignore their `ws`, place their slabs in the arena one after the other and record the fold; isa_slab_arena_flush
+ * adds every recorded slab set into its dw/dbias with one launch per 32 folds (~190 small launches fewer per
+ * training step at the BASELINE configuration).  When the arena cannot hold a call's slabs the call returns
+ * ISA_ENOMEM and launches nothing.  A handle is used by one host thread at a time; distinct handles are
+ * independent.  The region must not be reused before the flush's kernels have run.                        */
+int isa_slab_arena_create(float* region, int64_t region_floats, isa_slab_arena** out);
+int isa_slab_arena_destroy(isa_slab_arena* a);
+int isa_slab_arena_begin(isa_slab_arena* a);                 /* rewind; forget folds recorded but never flushed */
+int isa_slab_arena_flush(isa_slab_arena* a, void* stream, int32_t* n_folds, int64_t* floats_used);
 
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the
@@ -175,6 +184,17 @@ int isa_bn_finalize(const float* stats, float count, const float* gamma, const f
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* mean, float* invstd, int32_t c,
                     void* stream);
+/* Running-statistics updates of `n` train-mode layers, applied in array order by ONE launch per 64 layers: what
+ * isa_bn_finalize does to running_mean/var when it is given them.  For statistics produced on another HIP stream
+ * than the one that must own the update order (the decoder iterations run concurrently, attenet2.py:384-399 runs
+ * them one after the other: iteration 0 updates inside its finalize, iteration 1's updates are applied here after
+ * the join).  upd: HOST array, copied into the kernel arguments (a captured hipGraph keeps it by value). */
+typedef struct isa_bn_upd {
+    const float* stats;           /* [ISA_STAT_REPLICAS][2C] sums of the batch (device) */
+    float* running_mean; float* running_var;
+    float count; int32_t c;
+} isa_bn_upd;
+int isa_bn_running_update(const isa_bn_upd* upd, int32_t n, float momentum, void* stream);
 /* backward of t = act(scale*y+shift): reduce pass  red[2C] += (sum dz, sum dz*yhat),
  * then apply pass  dy = gamma*invstd*(dz - red0/count - yhat*red1/count)  (in place over dt ok) */
 int isa_bn_bwd_reduce(const isa_tensor* dt, const isa_tensor* y, const float* scale,
@@ -284,10 +304,11 @@ int isa_se_bwd(const isa_tensor* dxa, const isa_tensor* x, const float* gate, co
 /* dst (+)= src * s[n,c]  (Dropout2d backward on a residual sum) */
 int isa_scale_bc(const isa_tensor* src, const float* s_bc, const isa_tensor* dst, int32_t accumulate, void* stream);
 /* optimizer on the flat parameter buffer (model.py:145-166,273-278): out += sum (g*scale)^2, then
- * clip_grad_norm_(max_norm) + Adadelta(lr, rho, eps, weight_decay) in one pass */
+ * clip_grad_norm_(max_norm) + Adadelta(lr, rho, eps, weight_decay) in one pass.  lr_dev (optional, device float[1])
+ * overrides `lr` at run time, so a launch recorded in a hipGraph follows the scheduler (model.py:164,437). */
 int isa_sqnorm(const float* g, int64_t n, float scale, float* out /*zeroed*/, void* stream);
 int isa_adadelta(float* p, const float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps, float wd,
-                 const float* sqnorm, float max_norm, float gscale, void* stream);
+                 const float* sqnorm, float max_norm, float gscale, const float* lr_dev, void* stream);
 
 /* ---- the reference's named attention operators (modules/utils.py; dead at HEAD) --
  * a19 ScaledDotProductAttention.forward (utils.py:316-327): out[bh,lq,dv] = softmax(mask(q k^T / T)) v,

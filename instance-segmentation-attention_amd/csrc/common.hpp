@@ -197,16 +197,25 @@ __device__ __forceinline__ void block_sums_atomic(float (&a)[K], float* sh, floa
     }
 }
 
-// ---- deferred slab folds (isa_wgrad_defer_begin / isa_wgrad_defer_flush; defined in conv_wgrad.hip) ----
-// Weight gradients are leaves of the backward graph: nothing reads dW before the optimizer.  While deferral is
-// active the weight-gradient launchers take their partial-slab region from a step arena (defer_ws) and record the
-// second-stage fold (defer_push) instead of launching it; the flush folds every recorded slab set in a handful of
-// launches (descriptors travel as kernel arguments, so a captured hipGraph keeps them by value).
+// ---- deferred slab folds (isa_slab_arena_*; defined in conv_wgrad.hip) -------------------------------
+// Weight gradients are leaves of the backward graph: nothing reads dW before the optimizer.  A weight-gradient
+// entry point that is handed an isa_slab_arena takes its partial-slab region from the arena (defer_ws) and records
+// the second-stage fold in it (defer_push) instead of launching it; isa_slab_arena_flush folds every recorded slab
+// set in a handful of launches (descriptors travel as kernel arguments, so a captured hipGraph keeps them by
+// value).  All state lives in the caller's handle: no globals, no thread-locals.
+#include <vector>
 struct FoldDesc {
     const float* ws; float* dw; float* dbias; const int32_t* kmap;
     int kind;                    // 0: MFMA-fragment slabs (conv_wgrad family), 1: depthwise tile slabs [gx][gy][10*tk]
     int gx, gy, taps, groups_k, tn, tk, N, cin, ksrc, out_mode, rsplit;
     int first_block, blocks;
 };
-float* defer_ws(float* ws, long* ws_floats);          // arena cursor + remaining floats when deferring, else unchanged
-bool defer_push(FoldDesc d, long used_floats);        // true: recorded, the caller skips its own reduce launch
+struct isa_slab_arena {
+    float* base; long floats, used, peak;
+    bool from_arena;             // between a defer_ws that handed out arena memory and the defer_push that records it
+    std::vector<FoldDesc> tab;
+};
+// a == NULL: *ws / *ws_floats unchanged (immediate fold from the caller's workspace).  Otherwise the arena cursor and
+// the floats left; ISA_ENOMEM when less than the minimum slab budget is left (never a silent fallback).
+int defer_ws(isa_slab_arena* a, float** ws, long* ws_floats);
+bool defer_push(isa_slab_arena* a, FoldDesc d, long used_floats);   // true: recorded, the caller skips its own reduce launch

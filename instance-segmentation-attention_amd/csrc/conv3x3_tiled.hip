@@ -7,7 +7,8 @@
 #include "common.hpp"
 #include "tr_lds.hpp"
 
-int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s);
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps,
+                             isa_slab_arena* sa, hipStream_t s);
 
 namespace {
 
@@ -259,20 +260,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tiled_kernel(C3WParams p) {
 }  // namespace
 
 int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float* dw, float* dbias, float* ws, long ws_floats,
-                               hipStream_t s) {
+                               isa_slab_arena* sa, hipStream_t s) {
     C3WParams p{};
     p.x = (const bf16_t*)x->data; p.dy = (const bf16_t*)dy->data; p.n = x->n; p.h = x->h; p.w = x->w;
-    ws = defer_ws(ws, &ws_floats);
+    if (int rc = defer_ws(sa, &ws, &ws_floats)) return rc;
     p.cin = x->c; p.ldx = x->ld; p.N = dy->c; p.ldd = dy->ld; p.ws = ws;
     p.tiles_x = (p.w + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
     long gx = p.ntiles < 256 ? p.ntiles : 256;
     const long cap = ws_floats / (9L * (1024 + 32));
-    if (cap < 1) return ISA_EINVAL;
+    if (cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > cap) gx = cap;
     const size_t tiles = (size_t)HALO * WS_ + (size_t)TH * TW * WS_, redb = (9 * 1024 + 32) * 4;
     const size_t lds = tiles > redb ? tiles : redb;
     hipLaunchKernelGGL(conv3x3_wgrad_tiled_kernel, dim3((unsigned)gx), dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;
-    return wgrad_slab_reduce_launch(ws, dw, dbias, (int)gx, 1, 1, p.N, p.cin, 9, s);
+    return wgrad_slab_reduce_launch(ws, dw, dbias, (int)gx, 1, 1, p.N, p.cin, 9, sa, s);
 }

@@ -16,7 +16,8 @@
 #include "common.hpp"
 #include "tr_lds.hpp"
 
-int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s);
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps,
+                             isa_slab_arena* sa, hipStream_t s);
 
 namespace {
 
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int TN, int TK, int YACT, int XMODE>
-int launch_inst(PwParams& p, long ws_floats, hipStream_t s) {
+int launch_inst(PwParams& p, long ws_floats, isa_slab_arena* sa, hipStream_t s) {
     constexpr int SN = TrStride<TN * 32>::bytes, SK = TrStride<TK * 32>::bytes;
     constexpr size_t slab = (size_t)32 * (SN + SK) * 4 + 9 * 64 * 4;
     constexpr size_t redb = ((size_t)TN * TK * 16 * 64 + TN * 32) * 4;
@@ -304,21 +305,21 @@ int launch_inst(PwParams& p, long ws_floats, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long gx = (nchunks + 3) / 4;
     if (gx > 256 * 2) gx = 256 * 2;                                  // 2 resident workgroups per CU; fewer slabs to reduce
-    p.ws = defer_ws(p.ws, &ws_floats);
+    if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / slabf;
-    if (ws_cap < 1) return ISA_EINVAL;
+    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
     hipLaunchKernelGGL((pw_bn_bwd_kernel<TN, TK, YACT, XMODE>), dim3((unsigned)gx), dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;
-    return wgrad_slab_reduce_launch(p.ws, p.dw, nullptr, (int)gx, TN, TK, p.N, p.K, 1, s);
+    return wgrad_slab_reduce_launch(p.ws, p.dw, nullptr, (int)gx, TN, TK, p.N, p.K, 1, sa, s);
 }
 
 template <int TN, int TK>
-int launch_tile(PwParams& p, int xmode, long ws_floats, hipStream_t s) {
+int launch_tile(PwParams& p, int xmode, long ws_floats, isa_slab_arena* sa, hipStream_t s) {
     const bool y6 = p.yact == ISA_ACT_RELU6, y0 = p.yact == ISA_ACT_NONE;
-#define PW_X(YA) (xmode == 0 ? launch_inst<TN, TK, YA, 0>(p, ws_floats, s) \
-                : xmode == 1 ? launch_inst<TN, TK, YA, 1>(p, ws_floats, s) \
-                             : launch_inst<TN, TK, YA, 2>(p, ws_floats, s))
+#define PW_X(YA) (xmode == 0 ? launch_inst<TN, TK, YA, 0>(p, ws_floats, sa, s) \
+                : xmode == 1 ? launch_inst<TN, TK, YA, 1>(p, ws_floats, sa, s) \
+                             : launch_inst<TN, TK, YA, 2>(p, ws_floats, sa, s))
     if (y6) return PW_X(ISA_ACT_RELU6);
     if (y0) return PW_X(ISA_ACT_NONE);
     return PW_X(ACT_RT);
@@ -330,11 +331,12 @@ int launch_tile(PwParams& p, int xmode, long ws_floats, hipStream_t s) {
 extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y, const isa_bn_bwd* ybn,
                                        const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                                        const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
-                                       const isa_tensor* addend, float* ws, int64_t ws_floats, void* stream) {
+                                       const isa_tensor* addend, float* ws, int64_t ws_floats, isa_slab_arena* defer,
+                                       void* stream) {
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (g->dtype != ISA_BF16 || y->dtype != ISA_BF16 || x->dtype != ISA_BF16 || dx->dtype != ISA_BF16) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
-    if (!w || !dw || !ws) return ISA_EINVAL;
+    if (!w || !dw || (!ws && !defer)) return ISA_EINVAL;
     const int N = g->c, K = x->c;
     if (N > 64 || K > 64 || N % 8 || K % 8) return ISA_EINVAL;
     if (y->c != N || dx->c != K) return ISA_EINVAL;
@@ -362,8 +364,8 @@ extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y,
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
     hipStream_t s = as_stream(stream);
     const int tn = (N + 31) / 32, tk = (K + 31) / 32;
-    if (tn == 1 && tk == 1) return launch_tile<1, 1>(p, xmode, ws_floats, s);
-    if (tn == 1 && tk == 2) return launch_tile<1, 2>(p, xmode, ws_floats, s);
-    if (tn == 2 && tk == 1) return launch_tile<2, 1>(p, xmode, ws_floats, s);
-    return launch_tile<2, 2>(p, xmode, ws_floats, s);
+    if (tn == 1 && tk == 1) return launch_tile<1, 1>(p, xmode, ws_floats, defer, s);
+    if (tn == 1 && tk == 2) return launch_tile<1, 2>(p, xmode, ws_floats, defer, s);
+    if (tn == 2 && tk == 1) return launch_tile<2, 1>(p, xmode, ws_floats, defer, s);
+    return launch_tile<2, 2>(p, xmode, ws_floats, defer, s);
 }

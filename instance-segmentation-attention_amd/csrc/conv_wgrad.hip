@@ -21,6 +21,7 @@
 #include "tr_lds.hpp"
 
 int conv3x3_wgrad_tiled_launch(const isa_tensor* x, const isa_tensor* dy, float* dw, float* dbias, float* ws, long ws_floats,
+                               isa_slab_arena* sa,
                                hipStream_t s);     // conv3x3_tiled.hip
 
 namespace {
@@ -38,6 +39,7 @@ struct WgParams {
     int groups_k;
     long nchunks;
     long ws_floats;            // host side: capacity of ws
+    isa_slab_arena* sa;        // host side: deferred folds (may be NULL)
     float* ws;                 // [gridDim.x][gridDim.y][taps][TN*TK*1024 (+ TN*32 bias sums)] partial slabs
 };
 
@@ -306,14 +308,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(FoldChunk ch) {
     }
 }
 
-// thread-local deferral state (one Python thread drives a GPU; capture happens on the same thread)
-struct DeferState {
-    bool active = false, from_arena = false;
-    float* arena = nullptr; long arena_floats = 0, used = 0, peak = 0;
-    std::vector<FoldDesc> tab;
-};
-thread_local DeferState g_defer;
-constexpr long DEFER_MIN_FLOATS = 16L << 20;       // below this much arena left, fall back to the immediate fold
+constexpr long DEFER_MIN_FLOATS = 16L << 20;       // an arena with less than this left refuses the call (ISA_ENOMEM)
 
 static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipStream_t s) {
     const int slabf = tn * tk * 1024 + tn * 32;
@@ -324,9 +319,9 @@ static int launch_reduce(const WgParams& p, int gx, int gy, int tn, int tk, hipS
     if (rsplit > 64) rsplit = 64;
     if (rsplit > gx) rsplit = gx;
     if (rsplit < 1) rsplit = 1;
-    if (g_defer.active && g_defer.from_arena) {
+    if (p.sa && p.sa->from_arena) {
         FoldDesc d{p.ws, p.dw, p.dbias, p.kmap, 0, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode, 0, 0, 0};
-        if (defer_push(d, (long)gx * gy * p.taps * slabf)) return ISA_OK;
+        if (defer_push(p.sa, d, (long)gx * gy * p.taps * slabf)) return ISA_OK;
     }
     WgReduce q{p.ws, p.dw, p.dbias, p.kmap, gx, gy, p.taps, p.groups_k, tn, tk, p.N, p.cin, p.ksrc, p.out_mode, rsplit};
     dim3 grid(cdiv(slabf, 256), gy, p.taps * rsplit);
@@ -529,9 +524,9 @@ int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (nchunks + 3) / 4;
     long cap = (256L * 2) / ((long)gy * p.taps);
-    p.ws = defer_ws(p.ws, &p.ws_floats);
+    if (int rc = defer_ws(p.sa, &p.ws, &p.ws_floats)) return rc;
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
-    if (ws_cap < 1) return ISA_EINVAL;                    // workspace too small for even one slab set
+    if (ws_cap < 1) return p.sa ? ISA_ENOMEM : ISA_EINVAL;   // workspace too small for even one slab set
     if (cap > ws_cap) cap = ws_cap;
     if (cap < 1) cap = 1;
     const int gx = (int)(want < cap ? want : cap);
@@ -555,9 +550,9 @@ int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
     const long slabf = (long)TN * TK * 1024 + TN * 32;
     long want = (p.nchunks + 3) / 4;
     long cap = (256L * 2) / ((long)gy * p.taps);
-    p.ws = defer_ws(p.ws, &p.ws_floats);
+    if (int rc = defer_ws(p.sa, &p.ws, &p.ws_floats)) return rc;
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
-    if (ws_cap < 1) return ISA_EINVAL;
+    if (ws_cap < 1) return p.sa ? ISA_ENOMEM : ISA_EINVAL;
     if (cap > ws_cap) cap = ws_cap;
     if (cap < 1) cap = 1;
     const int gx = (int)(want < cap ? want : cap);
@@ -601,15 +596,15 @@ int dispatch_wg(WgParams& p, hipStream_t s) {
 extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                               float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
                               const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats,
-                              void* stream) {
-    if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype || !ws) return ISA_EINVAL;
+                              isa_slab_arena* defer, void* stream) {
+    if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype || (!ws && !defer)) return ISA_EINVAL;
     if (in_mode == ISA_IN_GATHER2) return ISA_EINVAL;
     WgParams p{};
     p.x = x->data; p.xh = x->h; p.xw = x->w; p.cin = x->c; p.ldx = x->ld;
     p.dy = dy->data; p.dh = dy->h; p.dw_ = dy->w; p.ldd = dy->ld;
     p.mh = x->h; p.mw = x->w; p.M = (long)x->n * x->h * x->w;
     p.pro = make_pro(pro); p.dw = dw; p.dbias = dbias; p.kmap = kmap; p.ksrc = ksrc > 0 ? ksrc : x->c;
-    p.in_mode = in_mode; p.out_mode = out_mode; p.ws = ws; p.ws_floats = ws_floats;
+    p.in_mode = in_mode; p.out_mode = out_mode; p.ws = ws; p.ws_floats = ws_floats; p.sa = defer;
     if (out_mode == ISA_OUT_SHUFFLE2) {
         if (in_mode != ISA_IN_1X1 || dy->h != 2 * x->h || dy->w != 2 * x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = 4; p.N = dy->c;
@@ -621,7 +616,7 @@ extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa
     p.nchunks = (p.M + PM - 1) / PM;
     if (in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && pro_trivial(p.pro) && !kmap &&
         x->c <= 32 && dy->c <= 32 && p.ksrc == x->c)
-        return conv3x3_wgrad_tiled_launch(x, dy, dw, dbias, ws, ws_floats, as_stream(stream));
+        return conv3x3_wgrad_tiled_launch(x, dy, dw, dbias, ws, ws_floats, defer, as_stream(stream));
     if (x->dtype == ISA_BF16) return dispatch_wg<bf16_t>(p, as_stream(stream));
     return dispatch_wg<float>(p, as_stream(stream));
 }
@@ -717,27 +712,29 @@ extern "C" int isa_colsum(const isa_tensor* x, float* out, void* stream) {
 
 // second-stage reduction for other translation units that write conv_wgrad-format slabs (conv_fused_bwd.hip,
 // conv3x3_tiled.hip): one tile group, `taps` slab sets per workgroup
-int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps, hipStream_t s) {
+int wgrad_slab_reduce_launch(float* ws, float* dw, float* dbias, int gx, int tn, int tk, int N, int cin, int taps,
+                             isa_slab_arena* sa, hipStream_t s) {
     WgParams p{};
+    p.sa = sa;
     p.ws = ws; p.dw = dw; p.dbias = dbias; p.kmap = nullptr; p.taps = taps; p.groups_k = 1; p.N = N; p.cin = cin;
     p.ksrc = cin; p.out_mode = ISA_OUT_PLAIN;
     return launch_reduce(p, gx, 1, tn, tk, s);
 }
 
 // ---- deferred folds ---------------------------------------------------------------------------------
-float* defer_ws(float* ws, long* ws_floats) {
-    DeferState& d = g_defer;
-    d.from_arena = false;
-    if (!d.active || d.arena_floats - d.used < DEFER_MIN_FLOATS) return ws;
-    d.from_arena = true;
-    *ws_floats = d.arena_floats - d.used;
-    return d.arena + d.used;
+int defer_ws(isa_slab_arena* a, float** ws, long* ws_floats) {
+    if (!a) return ISA_OK;
+    a->from_arena = false;
+    if (a->floats - a->used < DEFER_MIN_FLOATS) return ISA_ENOMEM;
+    a->from_arena = true;
+    *ws_floats = a->floats - a->used;
+    *ws = a->base + a->used;
+    return ISA_OK;
 }
 
-bool defer_push(FoldDesc f, long used_floats) {
-    DeferState& d = g_defer;
-    if (!d.active || !d.from_arena || f.ws != d.arena + d.used || used_floats > d.arena_floats - d.used) return false;
-    d.from_arena = false;
+bool defer_push(isa_slab_arena* a, FoldDesc f, long used_floats) {
+    if (!a || !a->from_arena || f.ws != a->base + a->used || used_floats > a->floats - a->used) return false;
+    a->from_arena = false;
     // ~32 slabs per adder (independent coalesced loads); the whole backward pass supplies the parallelism
     int rsplit = (f.gx + 31) / 32;
     if (rsplit > 64) rsplit = 64;
@@ -745,35 +742,43 @@ bool defer_push(FoldDesc f, long used_floats) {
     f.rsplit = rsplit;
     if (f.kind == 0) f.blocks = cdiv(f.tn * f.tk * 1024 + f.tn * 32, 256) * f.gy * f.taps * rsplit;
     else f.blocks = f.gy * rsplit;
-    d.tab.push_back(f);
-    d.used += (used_floats + 63) & ~63L;
-    if (d.used > d.peak) d.peak = d.used;
+    a->tab.push_back(f);
+    a->used += (used_floats + 63) & ~63L;
+    if (a->used > a->peak) a->peak = a->used;
     return true;
 }
 
-extern "C" int isa_wgrad_defer_begin(float* arena, int64_t arena_floats) {
-    if (!arena || arena_floats < DEFER_MIN_FLOATS || ((uintptr_t)arena & 255)) return ISA_EINVAL;
-    DeferState& d = g_defer;
-    d.active = true; d.from_arena = false; d.arena = arena; d.arena_floats = arena_floats; d.used = 0;
-    d.tab.clear();
+extern "C" int isa_slab_arena_create(float* region, int64_t region_floats, isa_slab_arena** out) {
+    if (!out || !region || region_floats < DEFER_MIN_FLOATS || ((uintptr_t)region & 255)) return ISA_EINVAL;
+    *out = new isa_slab_arena{region, (long)region_floats, 0, 0, false, {}};
     return ISA_OK;
 }
 
-extern "C" int isa_wgrad_defer_flush(void* stream, int32_t* n_folds, int64_t* arena_used) {
-    DeferState& d = g_defer;
-    if (!d.active) return ISA_EINVAL;
-    d.active = false;
-    if (n_folds) *n_folds = (int32_t)d.tab.size();
-    if (arena_used) *arena_used = d.used;
-    for (size_t i0 = 0; i0 < d.tab.size(); i0 += FOLD_CHUNK) {
+extern "C" int isa_slab_arena_destroy(isa_slab_arena* a) {
+    delete a;
+    return ISA_OK;
+}
+
+extern "C" int isa_slab_arena_begin(isa_slab_arena* a) {
+    if (!a) return ISA_EINVAL;
+    a->used = 0; a->from_arena = false;
+    a->tab.clear();
+    return ISA_OK;
+}
+
+extern "C" int isa_slab_arena_flush(isa_slab_arena* a, void* stream, int32_t* n_folds, int64_t* floats_used) {
+    if (!a) return ISA_EINVAL;
+    if (n_folds) *n_folds = (int32_t)a->tab.size();
+    if (floats_used) *floats_used = a->used;
+    for (size_t i0 = 0; i0 < a->tab.size(); i0 += FOLD_CHUNK) {
         FoldChunk ch;
-        ch.n = (int)(d.tab.size() - i0 < (size_t)FOLD_CHUNK ? d.tab.size() - i0 : FOLD_CHUNK);
+        ch.n = (int)(a->tab.size() - i0 < (size_t)FOLD_CHUNK ? a->tab.size() - i0 : FOLD_CHUNK);
         int blocks = 0;
-        for (int i = 0; i < ch.n; ++i) { ch.d[i] = d.tab[i0 + i]; ch.d[i].first_block = blocks; blocks += ch.d[i].blocks; }
+        for (int i = 0; i < ch.n; ++i) { ch.d[i] = a->tab[i0 + i]; ch.d[i].first_block = blocks; blocks += ch.d[i].blocks; }
         for (int i = ch.n; i < FOLD_CHUNK; ++i) ch.d[i] = FoldDesc{};
         if (blocks > 0) hipLaunchKernelGGL(wgrad_fold_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), ch);
-        if (launch_status() != ISA_OK) { d.tab.clear(); return ISA_ELAUNCH; }
+        if (launch_status() != ISA_OK) { a->tab.clear(); return ISA_ELAUNCH; }
     }
-    d.tab.clear();
+    a->tab.clear();
     return ISA_OK;
 }

@@ -17,7 +17,7 @@
 int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const float* bias, const isa_tensor* y,
                 float* stats, int accumulate, void* stream);
 int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, float* dw, float* dbias, int csrc,
-              float* ws, long ws_floats, void* stream);
+              float* ws, long ws_floats, isa_slab_arena* defer, void* stream);
 
 namespace {
 
@@ -354,13 +354,13 @@ extern "C" int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const is
 }
 
 extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
-                                   float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats,
+                                   float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, isa_slab_arena* defer,
                                    void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (x->n != dy->n || x->h != dy->h || x->w != dy->w || x->c != dy->c) return ISA_EINVAL;
-    if (!ws) return ISA_EINVAL;
+    if (!ws && !defer) return ISA_EINVAL;
     const int c8 = (x->c + 7) / 8 * 8;
-    if (x->ld >= c8 && dy->ld >= c8) return dw2_wgrad(x, pro, dy, dw, dbias, csrc, ws, ws_floats, stream);
+    if (x->ld >= c8 && dy->ld >= c8) return dw2_wgrad(x, pro, dy, dw, dbias, csrc, ws, ws_floats, defer, stream);
     if (10 * (size_t)x->c * 4 > 60 * 1024) return ISA_EINVAL;
     DwWgParams p{};
     p.x = x->data; p.dy = dy->data; p.dw = dw; p.dbias = dbias;

@@ -421,16 +421,16 @@ int launch_fwd2(Dw2Params& p, bool has_pro, hipStream_t s) {
 }
 
 template <typename T>
-int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, hipStream_t s) {
+int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, isa_slab_arena* sa, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
     const int ncb = (p.c + CB - 1) / CB;
     long gx = (256L * 2) / ncb;          // 2 resident workgroups per CU
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
-    p.ws = defer_ws(p.ws, &ws_floats);
+    if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / (10L * CB * ncb);
-    if (ws_cap < 1) return ISA_EINVAL;
+    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
     dim3 grid((unsigned)gx, ncb);
     const size_t lds = ((size_t)HALO * PS + 10 * CB) * 4;
@@ -438,7 +438,7 @@ int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, hipStream_t s) {
     else if (has_pro) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ACT_RT>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((dw2_wgrad_kernel<T, false, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;
-    if (defer_push(FoldDesc{p.ws, (float*)p.y, (float*)p.bias, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
+    if (defer_push(sa, FoldDesc{p.ws, (float*)p.y, (float*)p.bias, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
                    gx * ncb * 10L * CB)) return ISA_OK;
     hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, (float*)p.y, (float*)p.bias);
     return launch_status();
@@ -786,7 +786,7 @@ int launch_fused_inst(FusedParams& p, dim3 grid, hipStream_t s) {
 }
 
 template <typename T>
-int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
+int launch_fused(FusedParams& p, int xmode, long ws_floats, isa_slab_arena* sa, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
     p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
     const int ncb = (p.c + CB - 1) / CB;
@@ -794,9 +794,9 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     long gx = (256L * per_cu) / ncb;
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
-    p.ws = defer_ws(p.ws, &ws_floats);
+    if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / (10L * CB * ncb);
-    if (ws_cap < 1) return ISA_EINVAL;
+    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
     dim3 grid((unsigned)gx, ncb);
     int rc;
@@ -805,7 +805,7 @@ int launch_fused(FusedParams& p, int xmode, long ws_floats, hipStream_t s) {
     else if (xmode == 1) rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 1>(p, grid, s) : launch_fused_inst<T, ACT_RT, 1>(p, grid, s);
     else rc = y6 ? launch_fused_inst<T, ISA_ACT_RELU6, 2>(p, grid, s) : launch_fused_inst<T, ACT_RT, 2>(p, grid, s);
     if (rc != ISA_OK) return rc;
-    if (defer_push(FoldDesc{p.ws, p.dw, nullptr, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
+    if (defer_push(sa, FoldDesc{p.ws, p.dw, nullptr, nullptr, 1, (int)gx, ncb, 9, 1, 0, CB, p.c, 0, p.csrc, 0, 0, 0, 0},
                    gx * ncb * 10L * CB)) return ISA_OK;
     hipLaunchKernelGGL(dw2_wgrad_reduce_kernel, dim3(ncb, DW2_RSPLIT), dim3(256), 0, s, p.ws, (int)gx, ncb, p.c, p.csrc, p.dw, (float*)nullptr);
     return launch_status();
@@ -826,14 +826,14 @@ int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const fl
 }
 
 int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, float* dw, float* dbias, int csrc,
-              float* ws, long ws_floats, void* stream) {
+              float* ws, long ws_floats, isa_slab_arena* defer, void* stream) {
     Dw2Params p{};
     p.x = x->data; p.dy = dy->data; p.y = dw; p.bias = dbias;        // y/bias slots carry the output pointers
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldd = dy->ld;
     p.pro = make_pro(pro); p.ws = ws; p.csrc = (csrc > 0 && csrc < x->c) ? csrc : x->c;
     const bool has_pro = !pro_trivial(p.pro);
-    if (x->dtype == ISA_BF16) return launch_wg2<bf16_t>(p, has_pro, ws_floats, as_stream(stream));
-    return launch_wg2<float>(p, has_pro, ws_floats, as_stream(stream));
+    if (x->dtype == ISA_BF16) return launch_wg2<bf16_t>(p, has_pro, ws_floats, defer, as_stream(stream));
+    return launch_wg2<float>(p, has_pro, ws_floats, defer, as_stream(stream));
 }
 
 // Fused BN-apply + depthwise dgrad/wgrad + next BN-reduce; see dw_bn_bwd_kernel.
@@ -841,10 +841,10 @@ extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* 
                                          const isa_tensor* x, const isa_pro* xpro, const isa_bn_bwd* xbn,
                                          const void* w_flipped, float* dw, int32_t csrc,
                                          const isa_tensor* dx, int32_t accumulate, const isa_tensor* addend,
-                                         float* ws, int64_t ws_floats, void* stream) {
+                                         float* ws, int64_t ws_floats, isa_slab_arena* defer, void* stream) {
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
-    if (!w_flipped || !dw || !ws) return ISA_EINVAL;
+    if (!w_flipped || !dw || (!ws && !defer)) return ISA_EINVAL;
     if (x->c % 8 != 0) return ISA_EINVAL;
     const isa_tensor* ts[3] = {y, x, dx};
     for (const isa_tensor* t : ts)
@@ -870,6 +870,6 @@ extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* 
     p.csrc = (csrc > 0 && csrc < g->c) ? csrc : g->c;
     int xmode = 0;
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
-    if (g->dtype == ISA_BF16) return launch_fused<bf16_t>(p, xmode, ws_floats, as_stream(stream));
-    return launch_fused<float>(p, xmode, ws_floats, as_stream(stream));
+    if (g->dtype == ISA_BF16) return launch_fused<bf16_t>(p, xmode, ws_floats, defer, as_stream(stream));
+    return launch_fused<float>(p, xmode, ws_floats, defer, as_stream(stream));
 }

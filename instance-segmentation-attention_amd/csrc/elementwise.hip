@@ -84,6 +84,24 @@ __global__ void bn_finalize_kernel(const float* stats, float count, const float*
     }
 }
 
+// Ordered running-statistics updates of many train-mode BatchNorm layers in one launch (isa_bn_running_update):
+// one workgroup per layer; the descriptors travel by value so a captured hipGraph keeps them.
+constexpr int BN_UPD_CHUNK = 64;
+struct BnUpdChunk { isa_bn_upd d[BN_UPD_CHUNK]; };
+__global__ __launch_bounds__(256) void bn_running_update_kernel(BnUpdChunk ch, float momentum) {
+    const isa_bn_upd u = ch.d[blockIdx.x];
+    const int c = u.c;
+    for (int i = threadIdx.x; i < c; i += 256) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < ISA_STAT_R; ++r) { s1 += u.stats[r * 2 * c + i]; s2 += u.stats[r * 2 * c + c + i]; }
+        const float mean = s1 / u.count;
+        const float var = fmaxf(s2 / u.count - mean * mean, 0.f);
+        u.running_mean[i] = (1.f - momentum) * u.running_mean[i] + momentum * mean;
+        u.running_var[i] = (1.f - momentum) * u.running_var[i] + momentum * var * (u.count / fmaxf(u.count - 1.f, 1.f));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // generic vectorised NHWC walker
 // ------------------------------------------------------------------------------------------
@@ -535,6 +553,20 @@ extern "C" int isa_bn_finalize(const float* stats, float count, const float* gam
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), stats, count,
                        gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, c);
     return launch_status();
+}
+
+extern "C" int isa_bn_running_update(const isa_bn_upd* upd, int32_t n, float momentum, void* stream) {
+    if (n < 0 || (n > 0 && !upd)) return ISA_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!upd[i].stats || !upd[i].running_mean || !upd[i].running_var || upd[i].c <= 0 || !(upd[i].count > 0)) return ISA_EINVAL;
+    for (int i0 = 0; i0 < n; i0 += BN_UPD_CHUNK) {
+        BnUpdChunk ch{};
+        const int m = n - i0 < BN_UPD_CHUNK ? n - i0 : BN_UPD_CHUNK;
+        for (int i = 0; i < m; ++i) ch.d[i] = upd[i0 + i];
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3(m), dim3(256), 0, as_stream(stream), ch, momentum);
+        if (launch_status() != ISA_OK) return ISA_ELAUNCH;
+    }
+    return ISA_OK;
 }
 
 static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_tensor* dy,

@@ -629,7 +629,9 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, flo
     if (threadIdx.x == 0) atomicAdd(out, a);
 }
 __global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g, float* sq, float* acc, long n, float lr, float rho,
-                                                       float eps, float wd, const float* sqnorm, float max_norm, float gscale) {
+                                                       float eps, float wd, const float* sqnorm, float max_norm, float gscale,
+                                                       const float* lr_dev) {
+    if (lr_dev) lr = lr_dev[0];       // step size read at run time: a captured hipGraph follows ReduceLROnPlateau
     float clip = 1.f;
     if (max_norm > 0.f) { const float tn = sqrtf(sqnorm[0]); clip = fminf(1.f, max_norm / (tn + 1e-6f)); }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -796,9 +798,9 @@ extern "C" int isa_sqnorm(const float* g, int64_t n, float scale, float* out /* 
 }
 
 extern "C" int isa_adadelta(float* p, const float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps, float wd,
-                            const float* sqnorm, float max_norm, float gscale, void* stream) {
+                            const float* sqnorm, float max_norm, float gscale, const float* lr_dev, void* stream) {
     if (!p || !g || !sq || !acc || n <= 0) return ISA_EINVAL;
     hipLaunchKernelGGL(adadelta_kernel, dim3(grid_cap(cdiv(n, 256), 2048)), dim3(256), 0, as_stream(stream), p, g, sq, acc, (long)n, lr,
-                       rho, eps, wd, sqnorm, max_norm, gscale);
+                       rho, eps, wd, sqnorm, max_norm, gscale, lr_dev);
     return launch_status();
 }

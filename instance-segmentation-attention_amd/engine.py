@@ -9,6 +9,7 @@ Gradient convention: `Act.grad` is the gradient w.r.t. the TRUE value of the act
 lazy prologue).  Multi-consumer tensors accumulate: the first backward writer overwrites, later
 writers add (tracked per buffer and channel range) — no memsets of activation-sized buffers.
 """
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, List, Optional, Tuple
@@ -77,25 +78,41 @@ class Act:
 
 
 class Arena:
-    """Bump allocator whose allocations are replayed in the same order every step."""
+    """Bump allocator whose allocations are replayed in the same order every step.  One arena per
+    configuration (Engine.begin's key): a captured hipGraph holds raw pointers into its arena, so the
+    arena is frozen at capture time - a diverging allocation sequence then raises instead of freeing
+    memory the graph still writes to.  The arena also owns the step's zero-initialised fp32 scratch."""
 
     def __init__(self, device):
         self.device = device
         self.slots: List[torch.Tensor] = []
         self.cursor = 0
+        self.frozen = False
+        self.stats = None              # flat fp32 scratch zeroed once per step
+        self.stats_cursor = 0
+        self.keep: List[torch.Tensor] = []   # outgrown scratch buffers a captured graph may still reference
 
     def reset(self):
         self.cursor = 0
+        self.stats_cursor = 0
+        if self.stats is not None:
+            self.stats.zero_()
 
     def alloc(self, shape, dtype, zero=False):
         shape = tuple(int(s) for s in shape)
         if self.cursor < len(self.slots):
             t = self.slots[self.cursor]
             if tuple(t.shape) != shape or t.dtype != dtype:
+                if self.frozen:
+                    raise RuntimeError("arena of a captured hipGraph: allocation %d changed from %s %s to %s %s - "
+                                       "this configuration must keep its launch sequence (use another arena key)"
+                                       % (self.cursor, tuple(t.shape), t.dtype, shape, dtype))
                 # shape changed (new batch/size): drop the tail and start recording again
                 del self.slots[self.cursor:]
                 t = None
         else:
+            if self.frozen:
+                raise RuntimeError("arena of a captured hipGraph: the step allocates more buffers than were captured")
             t = None
         if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.device)
@@ -103,6 +120,23 @@ class Arena:
         self.cursor += 1
         if zero:
             t.zero_()
+        return t
+
+    def scratch(self, numel) -> torch.Tensor:
+        """fp32 scratch that is zero at step start (BN sums, reductions)."""
+        numel = rup(numel, 4)
+        if self.stats is None or self.stats_cursor + numel > self.stats.numel():
+            if self.frozen:
+                raise RuntimeError("arena of a captured hipGraph: the step needs more zeroed scratch than was captured")
+            # grow: only legal while recording a new configuration (first step)
+            new = torch.zeros(max(2 * (self.stats_cursor + numel), 1 << 16), dtype=torch.float32,
+                              device=self.device)
+            if self.stats is not None:
+                new[:self.stats.numel()].copy_(self.stats)
+                self.keep.append(self.stats)
+            self.stats = new
+        t = self.stats[self.stats_cursor:self.stats_cursor + numel]
+        self.stats_cursor += numel
         return t
 
     def bytes(self):
@@ -200,6 +234,7 @@ class Packer:
         self.buf = None
         self.table = None
         self.kmap_dev = None
+        self._keep = []          # outgrown buffers/tables: a captured hipGraph's launches may still reference them
 
     def add(self, name, variant, kind, n, k, taps, kp, rows, kmap=None):
         key = (name, variant)
@@ -227,7 +262,10 @@ class Packer:
 
     def finalize(self):
         dev = self.params.device
+        self._keep.extend(t for t in (self.table, self.kmap_dev) if t is not None)
         if self.buf is None or self.buf.numel() < self.total:
+            if self.buf is not None:
+                self._keep.append(self.buf)
             self.buf = torch.zeros(max(self.total, 16), dtype=self.dtype, device=dev)
         arr = (L.IsaPackEntry * len(self.entries))()
         for i, e in enumerate(self.entries):
@@ -256,23 +294,54 @@ class Packer:
         return C.c_void_p(self.kmap_dev.data_ptr() + 4 * e["kmap_off"])
 
 
+class Tape(list):
+    """Backward tape.  Entries are (closure, stream id) - a closure runs in the backward pass on the stream its
+    forward ran on - or (None, (src, dst)): a forward dependency `dst waits for src`, which the backward pass
+    replays reversed (src waits for dst).  See Engine.on / Engine.sync."""
+
+    def __init__(self, eng):
+        super().__init__()
+        self.eng = eng
+
+    def append(self, fn):
+        list.append(self, (fn, self.eng.cur))
+
+    def mark_sync(self, src, dst):
+        list.append(self, (None, (src, dst)))
+
+    def last_fn(self):
+        """The closure appended last, or a unique object when the tape is empty or ends in a sync edge."""
+        return self[-1][0] if (self and self[-1][0] is not None) else Tape
+
+
 class GradBook:
     """Gradient buffers mirror activation buffers; tracks which channel ranges were written."""
 
-    def __init__(self, arena: Arena):
-        self.arena = arena
+    def __init__(self, eng):
+        self.eng = eng
         self.bufs: Dict[int, torch.Tensor] = {}
         self.written: Dict[int, List[Tuple[int, int]]] = {}
 
     def reset(self):
         self.bufs.clear()
         self.written.clear()
+        self.shared: Dict[int, torch.Tensor] = {}     # activation buffers read by several concurrent branches
+
+    def share(self, a: Act):
+        """Mark a tensor whose consumers run on different streams (the decoder iterations all read the backbone
+        features): each side stream accumulates its gradient in a buffer of its own, merge_shared() adds them."""
+        self.shared[a.buf.data_ptr()] = a.buf
+
+    def _key(self, a: Act):
+        p = a.buf.data_ptr()
+        cur = self.eng.cur
+        return (p, cur) if (cur != 0 and p in self.shared) else p
 
     def grad_of(self, a: Act) -> Act:
-        key = a.buf.data_ptr()
+        key = self._key(a)
         g = self.bufs.get(key)
         if g is None:
-            g = self.arena.alloc(a.buf.shape, a.buf.dtype)
+            g = self.eng.arena.alloc(a.buf.shape, a.buf.dtype)
             self.bufs[key] = g
             self.written[key] = []
         return Act(g, a.c0, a.c)
@@ -300,7 +369,7 @@ class GradBook:
     def claim(self, a: Act, eng) -> int:
         """Called by a backward writer about to write grad_of(a).  Returns the `accumulate` flag
         and marks the range written; zero-fills gaps when the range is partially written."""
-        key = a.buf.data_ptr()
+        key = self._key(a)
         if key not in self.bufs:
             self.grad_of(a)
         lo, hi = a.c0, a.c0 + a.c
@@ -317,11 +386,31 @@ class GradBook:
         return 1
 
     def has(self, a: Act) -> bool:
-        key = a.buf.data_ptr()
+        key = self._key(a)
         if key not in self.bufs:
             return False
         full, _, _ = self._covered(key, a.c0, a.c0 + a.c)
         return full
+
+    def merge_shared(self, eng):
+        """On the main stream, after every side stream has been joined: add the side streams' gradients of the
+        shared tensors into the main buffers."""
+        assert eng.cur == 0
+        for key in [k for k in self.bufs if isinstance(k, tuple)]:
+            p, _ = key
+            side = self.bufs[key]
+            segs, merged = sorted(self.written[key]), []
+            for lo, hi in segs:
+                if merged and lo <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], hi)
+                else:
+                    merged.append([lo, hi])
+            for lo, hi in merged:
+                a = Act(self.shared[p], lo, hi - lo)
+                acc = self.claim(a, eng)
+                L.check(eng.lib.isa_axpy(Act(side, lo, hi - lo).d(), self.grad_of(a).d(), 1.0, acc, eng.st()),
+                        "isa_axpy(merge shared grad)")
+            self.written[key] = []
 
 
 class _ProfiledLib:
@@ -362,15 +451,17 @@ class Engine:
         self.dtype = dtype
         self.device = device
         self.packer = Packer(params, dtype)
-        self.arena = Arena(device)
-        self.grads = GradBook(self.arena)
-        self.tape: List = []
+        self.arenas: Dict[object, Arena] = {}      # one per configuration key (see begin)
+        self.arena = self.arenas.setdefault(None, Arena(device))
+        self.grads = GradBook(self)
+        self.tape = Tape(self)
+        self.cur = 0                   # stream id ops are issued on (0 = the step's own stream), see on()
+        self.side_streams: Dict[int, torch.cuda.Stream] = {}
+        self.main_stream = None
+        self.defer_bn_running = False  # finalize leaves the running statistics to flush_bn_running()
+        self.bn_running_queue: List[tuple] = []
         self.bn_train = False          # batch statistics + running-stat updates
         self.record = False            # build the backward tape
-        self.stats = None              # flat fp32 scratch zeroed once per step
-        self.stats_cursor = 0
-        self.stats_size = 0
-        self._zero = None
         self.lib = _ProfiledLib(L.lib(), self)
         self.ws = torch.empty(16 << 20, dtype=torch.float32, device=device)   # 64 MB reduction workspace
         self.profile = False           # when True every launch is bracketed by HIP events
@@ -384,49 +475,130 @@ class Engine:
         self.fuse_pw_bn = os.environ.get("ISA_FUSE_PW_BN", "1") != "0"
         self._pw_out: Dict[tuple, dict] = {}
         self._pw_in: Dict[tuple, dict] = {}      # conv input -> the same records: residual gradients ride along
-        self.eval_bn_cache: Dict[str, tuple] = {}   # eval-mode BN constants per layer; cleared when parameters change
-        # Opt-in experiment (ISA_SIDE_WGRAD=1): weight gradients of the un-fused convolutions are leaves of the
-        # backward graph, so they can run on a second HIP stream (own slab workspace) next to the data-gradient
-        # chain.  Measured under hipGraph replay: 42.6 ms/step vs 41.3 on one stream (the extra graph edges cost
-        # more than the overlap recovers), hence off by default.
-        self.side_wgrad = os.environ.get("ISA_SIDE_WGRAD", "0") == "1"
-        self.side_stream = None
-        self.ws_side = None
-        self._side_used = False
-        # Deferred weight-gradient folds (isa_wgrad_defer_begin/_flush): the ~270 second-stage fold launches of a
-        # backward pass collapse into ~9 at its end; partial slabs live in their own arena until then.
-        # ISA_DEFER_FOLD=0 restores the immediate folds (A/B measurements).
-        self.defer_fold = os.environ.get("ISA_DEFER_FOLD", "1") != "0"
+        # eval-mode BN constants per layer: persistent buffers (a captured inference graph reads them), recomputed in
+        # place by refresh_eval_bn() after the parameters changed
+        self.eval_bn_cache: Dict[str, tuple] = {}
+        self.eval_bn_stale = False
+        # Deferred weight-gradient folds (isa_slab_arena_*): the ~270 second-stage fold launches of a backward pass
+        # collapse into ~9 at its end; partial slabs live in their own arena until then.  The same arena gives every
+        # weight-gradient call a slab region of its own, which concurrent streams need anyway.
         self.fold_arena = None
+        self.slab = None               # isa_slab_arena* handle
         self.fold_stats = (0, 0)       # (folds, arena floats) of the last backward pass
+        self._deferring = False
+        self.defer_fold = os.environ.get("ISA_DEFER_FOLD", "1") != "0"    # 0: immediate folds (A/B, single stream only)
 
     # ------------------------------------------------------------------ step lifecycle
-    def begin(self, bn_train: bool, record: bool):
-        self.arena.reset()
+    def begin(self, bn_train: bool, record: bool, key=None):
+        """Start a step.  `key` names the configuration (mode, shapes, iteration count ...): each key owns its
+        arena, so an eval forward between two replays of a captured training graph cannot free or reshape the
+        buffers that graph points to (Arena.frozen turns a diverging sequence into an error)."""
+        akey = (bool(bn_train), bool(record), key)
+        arena = self.arenas.get(akey)
+        if arena is None:
+            arena = self.arenas[akey] = Arena(self.device)
+        self.arena = arena
+        arena.reset()
         self.grads.reset()
-        self.tape = []
+        self.tape = Tape(self)
+        self.cur = 0
+        self.main_stream = torch.cuda.current_stream()
+        self.defer_bn_running = False
+        self.bn_running_queue = []
         self._dw_out = {}
         self._pw_out = {}
         self._pw_in = {}
         self.bn_train, self.record = bn_train, record
-        self.stats_cursor = 0
-        if self.stats is not None:
-            self.stats.zero_()
+        if not bn_train and self.eval_bn_stale:
+            self.refresh_eval_bn()
+
+    def freeze_arena(self):
+        """Called after a hipGraph captured the current configuration."""
+        self.arena.frozen = True
+
+    # ------------------------------------------------------------------ concurrent branches (HIP streams)
+    def _stream(self, sid):
+        if sid == 0:
+            return self.main_stream
+        st = self.side_streams.get(sid)
+        if st is None:
+            st = self.side_streams[sid] = torch.cuda.Stream(device=self.device)
+        return st
+
+    @contextlib.contextmanager
+    def on(self, sid):
+        """Issue the enclosed ops on stream `sid` (0 = the step's own stream).  Their backward closures run on the
+        same stream.  Data that crosses streams needs an explicit sync() edge."""
+        prev = self.cur
+        self.cur = sid
+        try:
+            if sid == 0:
+                with torch.cuda.stream(self.main_stream):
+                    yield
+            else:
+                assert self.defer_fold or not self.record, "concurrent branches need the slab arena (ISA_DEFER_FOLD=1)"
+                with torch.cuda.stream(self._stream(sid)):
+                    yield
+        finally:
+            self.cur = prev
+
+    def _wait(self, src, dst):
+        if src == dst:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self._stream(src))
+        self._stream(dst).wait_event(ev)
+
+    def sync(self, src, dst):
+        """Forward edge: everything issued so far on stream `src` happens before what follows on `dst`.  Recorded on
+        the tape, so the backward pass replays the edge reversed (the gradients flow dst -> src)."""
+        self._wait(src, dst)
+        if self.record:
+            self.tape.mark_sync(src, dst)
+
+    def flush_bn_running(self):
+        """Apply the running-statistics updates queued while defer_bn_running was set, in queue order, on the
+        current stream (one launch per 64 layers)."""
+        q = self.bn_running_queue
+        if not q:
+            return
+        arr = (L.IsaBnUpd * len(q))()
+        P = self.params
+        for i, (stats, count, pre, c) in enumerate(q):
+            arr[i] = L.IsaBnUpd(stats.data_ptr(), P.ptr(pre + ".running_mean").value, P.ptr(pre + ".running_var").value,
+                                count, c)
+        L.check(self.lib.isa_bn_running_update(arr, len(q), self.BN_MOMENTUM, self.st()), "isa_bn_running_update")
+        self.bn_running_queue = []
+
+    def _finalize_train(self, stats, count, pre, c, scale, shift, mean, invstd):
+        P = self.params
+        defer = self.defer_bn_running
+        L.check(self.lib.isa_bn_finalize(L.ptr(stats), count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                         None if defer else P.ptr(pre + ".running_mean"),
+                                         None if defer else P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
+                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
+                "isa_bn_finalize")
+        if defer:
+            self.bn_running_queue.append((stats, count, pre, c))
+        P.int_buffers[pre + ".num_batches_tracked"] += 1
+
+    def defer_handle(self):
+        """isa_slab_arena* for the weight-gradient entry points while a backward pass runs, else NULL."""
+        return self.slab if (self._deferring and self.defer_fold) else None
+
+    def refresh_eval_bn(self):
+        """Recompute the cached eval-mode BN constants in place (same buffers: captured graphs keep reading them)."""
+        P = self.params
+        for pre, (scale, shift, mean, invstd) in self.eval_bn_cache.items():
+            L.check(self.lib.isa_bn_finalize(None, 1.0, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                             P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
+                                             self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
+                                             L.ptr(invstd), scale.numel(), self.st()), "isa_bn_finalize(eval refresh)")
+        self.eval_bn_stale = False
 
     def scratch(self, numel) -> torch.Tensor:
         """fp32 scratch that is zero at step start (BN sums, reductions)."""
-        numel = rup(numel, 4)
-        if self.stats is None or self.stats_cursor + numel > self.stats.numel():
-            # grow: only legal while recording a new configuration (first step)
-            new = torch.zeros(max(2 * (self.stats_cursor + numel), 1 << 16), dtype=torch.float32,
-                              device=self.device)
-            if self.stats is not None:
-                new[:self.stats.numel()].copy_(self.stats)
-                self._stale_stats = True
-            self.stats = new
-        t = self.stats[self.stats_cursor:self.stats_cursor + numel]
-        self.stats_cursor += numel
-        return t
+        return self.arena.scratch(numel)
 
     def f32(self, *shape):
         return self.arena.alloc(shape, torch.float32)
@@ -485,7 +657,7 @@ class Engine:
                     and kmap is None and bias is None and x.needs_grad and out.c <= 64 and x.c <= 64 \
                     and out.c % 8 == 0 and x.c % 8 == 0 and (x.pro is None or x.pro.bscale is None):
                 xb = getattr(x, "bn", None)
-                ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
+                ok_x = xb is not None and xb["train"] and self.tape.last_fn() is xb.get("bwd_fn")
                 info = dict(xbn=xb if ok_x else None, ybn=None, addend=None, done=False)
                 self._pw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
                 self._pw_in[(x.buf.data_ptr(), x.c0, x.c)] = info
@@ -507,7 +679,7 @@ class Engine:
                         L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname), None,
                                                         L.IN_1X1, L.OUT_SHUFFLE2, pk.kmap_ptr(reg["fwd"]),
                                                         self.params.shapes[wname][0], L.ptr(ws), ws.numel(),
-                                                        self.st()), "isa_conv_wgrad")
+                                                        self.defer_handle(), self.st()), "isa_conv_wgrad")
                         if bias is not None:
                             L.check(self.lib.isa_colsum(dy.d(), self.params.gptr(bias), self.st()), "isa_colsum")
                     else:
@@ -517,12 +689,8 @@ class Engine:
                                                         self.params.gptr(bias) if bias else None, in_mode,
                                                         L.OUT_PLAIN, pk.kmap_ptr(reg["fwd"]),
                                                         self.params.shapes[wname][1], L.ptr(ws), ws.numel(),
-                                                        self.st()), "isa_conv_wgrad")
-                if self.side_wgrad and x.needs_grad:          # a leaf: overlaps the data-gradient chain
-                    with self._on_side():
-                        wgrad(self.ws_side)
-                else:
-                    wgrad(self.ws)
+                                                        self.defer_handle(), self.st()), "isa_conv_wgrad")
+                wgrad(self.ws)
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
                     dx = self.grads.grad_of(x)
@@ -564,7 +732,7 @@ class Engine:
             g.d(), yb["raw"].d(), C.byref(ydesc), x.d(), x.p(), C.byref(xdesc) if xdesc is not None else None,
             self.params.ptr(wname), self.params.gptr(wname), self.grads.grad_of(x).d(), acc,
             info["addend"].d() if info["addend"] is not None else None,
-            L.ptr(self.ws), self.ws.numel(), self.st()), "isa_conv1x1_bn_backward")
+            L.ptr(self.ws), self.ws.numel(), self.defer_handle(), self.st()), "isa_conv1x1_bn_backward")
 
     def _launch_conv(self, x, reg, bias, out, in_mode, out_mode, st):
         if self.packer.table is None:
@@ -601,7 +769,7 @@ class Engine:
                 # "reduce" can be produced here when that BN was recorded immediately before this conv,
                 # so every other consumer of x has already accumulated its gradient when we run
                 xb = getattr(x, "bn", None)
-                ok_x = xb is not None and xb["train"] and self.tape and self.tape[-1] is xb.get("bwd_fn")
+                ok_x = xb is not None and xb["train"] and self.tape.last_fn() is xb.get("bwd_fn")
                 info = dict(xbn=xb if ok_x else None, ybn=None, addend=None, done=False)
                 self._dw_out[(out.buf.data_ptr(), out.c0, out.c)] = info
                 if x.pro is None and xb is None:                                  # plain tensor: residual gradients may ride along
@@ -633,14 +801,14 @@ class Engine:
                         C.byref(xdesc) if xdesc is not None else None, self.packer.ptr(reg["dgrad"]),
                         self.params.gptr(wname), self.params.shapes[wname][0], self.grads.grad_of(x).d(), acc,
                         info["addend"].d() if info["addend"] is not None else None,
-                        L.ptr(self.ws), self.ws.numel(), self.st()), "isa_dwconv3x3_bn_backward")
+                        L.ptr(self.ws), self.ws.numel(), self.defer_handle(), self.st()), "isa_dwconv3x3_bn_backward")
                     return
                 if self.profile:
                     self.next_bytes = 2 * nb
                 L.check(self.lib.isa_dwconv3x3_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
                                                      self.params.gptr(bias) if bias else None,
                                                      self.params.shapes[wname][0], L.ptr(self.ws), self.ws.numel(),
-                                                     self.st()), "isa_dwconv3x3_wgrad")
+                                                     self.defer_handle(), self.st()), "isa_dwconv3x3_wgrad")
                 if x.needs_grad:
                     acc = self.grads.claim(x, self)
                     if self.profile:
@@ -667,14 +835,13 @@ class Engine:
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
-        if cached is None:
-            L.check(self.lib.isa_bn_finalize(L.ptr(stats) if train else None, count, P.ptr(pre + ".weight"),
-                                             P.ptr(pre + ".bias"), P.ptr(pre + ".running_mean"),
-                                             P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
-                                             L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
-                    "isa_bn_finalize")
         if train:
-            P.int_buffers[pre + ".num_batches_tracked"] += 1
+            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd)
+        elif cached is None:
+            L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                             P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
+                                             self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
+                                             L.ptr(invstd), c, self.st()), "isa_bn_finalize")
         lazy = raw.with_pro(Pro(scale, shift, act))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
@@ -738,14 +905,13 @@ class Engine:
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
-        if cached is None:
-            L.check(self.lib.isa_bn_finalize(L.ptr(stats) if train else None, count, P.ptr(pre + ".weight"),
-                                             P.ptr(pre + ".bias"), P.ptr(pre + ".running_mean"),
-                                             P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
-                                             L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
-                    "isa_bn_finalize")
         if train:
-            P.int_buffers[pre + ".num_batches_tracked"] += 1
+            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd)
+        elif cached is None:
+            L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                             P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
+                                             self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
+                                             L.ptr(invstd), c, self.st()), "isa_bn_finalize")
         lazy = raw.with_pro(Pro(scale, shift, act, bscale))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
@@ -838,34 +1004,32 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward driver
-    def _on_side(self):
-        """Fork: the side stream waits for everything issued so far on the current stream."""
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream()
-            self.ws_side = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.side_stream.wait_event(ev)
-        self._side_used = True
-        return torch.cuda.stream(self.side_stream)
-
     def backward(self):
-        if self.defer_fold:
+        """Run the tape in reverse.  Closures run on the stream their forward ran on; forward sync edges are
+        replayed reversed.  Weight-gradient slabs go to the slab arena, folded once at the end (main stream, after
+        every side stream has been joined by the reversed fork edges)."""
+        if self.slab is None:
             if self.fold_arena is None:
                 self.fold_arena = torch.empty(int(os.environ.get("ISA_FOLD_ARENA_MB", "2048")) << 18,
                                               dtype=torch.float32, device=self.device)
-            L.check(self.lib.isa_wgrad_defer_begin(L.ptr(self.fold_arena), self.fold_arena.numel()),
-                    "isa_wgrad_defer_begin")
+            h = C.c_void_p()
+            L.check(self.lib.isa_slab_arena_create(L.ptr(self.fold_arena), self.fold_arena.numel(), C.byref(h)),
+                    "isa_slab_arena_create")
+            self.slab = h
+        L.check(self.lib.isa_slab_arena_begin(self.slab), "isa_slab_arena_begin")
+        self._deferring = True
         try:
-            for fn in reversed(self.tape):
-                fn()
+            for fn, tag in reversed(self.tape):
+                if fn is None:
+                    src, dst = tag
+                    self._wait(dst, src)
+                else:
+                    with self.on(tag):
+                        fn()
         finally:
-            if self._side_used:                      # join before the folds / optimizer / all-reduce read slabs and gradients
-                torch.cuda.current_stream().wait_stream(self.side_stream)
-                self._side_used = False
-            if self.defer_fold:
-                nf, used = C.c_int32(0), C.c_int64(0)
-                L.check(self.lib.isa_wgrad_defer_flush(self.st(), C.byref(nf), C.byref(used)),
-                        "isa_wgrad_defer_flush")
-                self.fold_stats = (nf.value, used.value)
-        self.tape = []
+            self._deferring = False
+            nf, used = C.c_int32(0), C.c_int64(0)
+            L.check(self.lib.isa_slab_arena_flush(self.slab, self.st(), C.byref(nf), C.byref(used)),
+                    "isa_slab_arena_flush")
+            self.fold_stats = (nf.value, used.value)
+        self.tape = Tape(self)

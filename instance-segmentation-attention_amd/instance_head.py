@@ -14,6 +14,7 @@ What changes vs. the reference's control flow (same results, MI355X-first):
     starts 16-byte aligned; conv1's weight columns are permuted to match when packed.
 """
 import math
+import os
 
 import torch
 
@@ -35,6 +36,9 @@ class InstanceHead:
         self.net = net
         self.E: Engine = net.E
         self.drop_rate = DROP_RATE
+        # concurrent HIP streams for the pyramid passes: 1 = none, 2 = odd iterations on a side stream, 3 = cross
+        # chains on the step's stream + one side stream per iteration's level chain (see forward)
+        self.streams = int(os.environ.get("ISA_STREAMS", "2"))
         self.sample_in_training = True   # False: greedy point (argmax) also in training; parity tests inject s_t instead
         import ctypes as _C
         self._level_w = (_C.c_float * 5)(*PYRAMID_W)
@@ -172,11 +176,12 @@ class InstanceHead:
         self._mask_cursor += n * c
         return m
 
-    def level(self, lvl, x_prev: Act, skip: Act, pred_prev: Act, mask_all, s_t, W_full, training, masks):
-        """One UpDecoderLayer (utils.py:869-892).  Returns (x, pred)."""
+    def level_cross(self, lvl, skip: Act, masks):
+        """The `cross` branch of one UpAttenLayer (utils.py:1058-1075): IR -> Dropout2d(module) -> IR on the backbone
+        feature.  It does not depend on the previous level, so it runs on its own stream next to the level chain.
+        Returns the concat buffer (its cross slice written) and the slice geometry."""
         E, net = self.E, self.net
-        pre = "decoder.bone.upAtten%d" % lvl
-        ua = pre + ".UpAtten"
+        ua = "decoder.bone.upAtten%d.UpAtten" % lvl
         n, h, w = skip.n, skip.h, skip.w
         out_ch, f = OUT_CH[lvl], FACTORS[lvl]
         nb = int(math.log2(f))
@@ -185,10 +190,22 @@ class InstanceHead:
         width = out_ch if lvl == 0 else 2 * out_ch
         cat = E.new_act(n, h, w, width, ld=width)
         cross_off = 0 if lvl == 0 else out_ch
-        # cross branch: IR -> Dropout2d(module) -> IR
         mid = E.new_act(n, h, w, out_ch)
         net.block_ir(skip, ua + ".cross.up_feature.0", mid, oscale=masks.get("cross"))
         net.block_ir(mid, ua + ".cross.up_feature.2", cat.slice(cross_off, ccross))
+        return cat
+
+    def level_main(self, lvl, cat: Act, x_prev: Act, pred_prev: Act, mask_all, s_t, W_full, training, masks):
+        """The rest of one UpDecoderLayer (utils.py:869-892) once the cross slice of `cat` is there.  Returns (x, pred)."""
+        E, net = self.E, self.net
+        pre = "decoder.bone.upAtten%d" % lvl
+        ua = pre + ".UpAtten"
+        n, h, w = cat.n, cat.h, cat.w
+        out_ch, f = OUT_CH[lvl], FACTORS[lvl]
+        nb = int(math.log2(f))
+        naux = 2 * nb + 2
+        ccross = out_ch - naux
+        cross_off = 0 if lvl == 0 else out_ch
         up = None
         if lvl > 0:
             up = E.new_act(n, h, w, out_ch)
@@ -283,6 +300,8 @@ class InstanceHead:
         if capture is not None:
             capture.update(x_enc=x_enc, s_sp=s, merge=merge)
         self._draw_masks(n, max_iter, training)
+        # ---- per-iteration front: instance softmax, glimpse point, pyramid targets (main stream) ----------------
+        pre = []
         for it in range(max_iter):
             idx = idx_dev[it]
             alpha, rowstat = E.f32(n * Lp), E.f32(2 * n)
@@ -305,10 +324,33 @@ class InstanceHead:
                 L.check(E.lib.isa_pool_target(L.ptr(ins), L.ptr(idx), None, nobj, n, H, W, f, L.ptr(t), E.st()),
                         "isa_pool_target")
                 targets.append(t)
-            x, pred = None, None
-            preds = []
             sums_all = E.scratch(5 * 8 * n)                 # [level][image][8], contiguous for isa_head_loss
-            sums = [sums_all[l * 8 * n:(l + 1) * 8 * n] for l in range(5)]
+            pre.append((idx, alpha, s_t, targets, sums_all))
+        # ---- the pyramid passes.  The iterations share weights and backbone features but not data (attenet2.py:384-
+        # 399 runs them one after the other), and inside an iteration the cross branch of every level only reads the
+        # backbone.  Most of these launches are too small to fill 256 CUs (16x16 ... 64x64 maps), so independent
+        # chains run on separate HIP streams.  streams == 2 (default): odd iterations run whole on side stream 1, one
+        # fork and one join per pass (34.3 -> 30.0 ms/step at the BASELINE shape under hipGraph replay).  streams == 3:
+        # the cross chains of all iterations stay on the step's own stream, the level chain of iteration i runs on
+        # side stream 1 + i % 2, one edge per level; measured slower (31.9 ms: every extra cross-stream edge costs
+        # more than the finer overlap returns; cross chains on their own side streams 32.4 - 33.9 ms).  Every edge has
+        # the origin stream at one end: hipGraph capture of side -> side edges crashes inside ROCm 7.2's
+        # hipStreamEndCapture (scripts/graph_probe.py).
+        # What the sequential order guaranteed is restored explicitly: BatchNorm running statistics of work that
+        # runs beside iteration 0 are applied after the join in iteration order (isa_bn_running_update), gradients of
+        # backbone features read from a side stream are accumulated per stream and merged (GradBook.merge_shared),
+        # loss assembly stays on the origin stream.
+        nstreams = self.streams if max_iter >= 2 else 1
+        assert nstreams in (1, 2, 3), "ISA_STREAMS must be 1, 2 or 3"
+        for sk in skips:
+            E.grads.share(sk)
+        if E.record and nstreams > 1:
+            E.tape.append(lambda: E.grads.merge_shared(E))      # runs after the reversed forks have joined stream 0
+        forked = [] if nstreams == 1 else ([1] if nstreams == 2 else [1, 2][:max_iter])
+        for sid in forked:                  # all forks up front: a fork issued later would wait for iteration 0's chain
+            E.sync(0, sid)
+        masks_of = {}
+        for it in range(max_iter):          # Dropout2d masks in the reference's call order (iteration-major)
             for lvl in range(5):
                 masks = {}
                 if self.drop_rate > 0:
@@ -316,13 +358,43 @@ class InstanceHead:
                     masks = dict(cross=self._drop_mask(n, oc, E.bn_train), d1=self._drop_mask(n, oc, training),
                                  d2=self._drop_mask(n, oc, training))
                     masks = {k: v for k, v in masks.items() if v is not None}
-                x, pred = self.level(lvl, x, skips[lvl], pred, mask_all[lvl], s_t, W, training, masks)
-                L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None, L.ptr(sums[lvl]), E.st()),
-                        "isa_mask_loss_sums")
-                preds.append(pred)
+                masks_of[it, lvl] = masks
+        state = [dict(x=None, pred=None, preds=[]) for _ in range(max_iter)]
+        for lvl in range(5):                # level-major issue order: the cross chains of all iterations interleave
+            for it in range(max_iter):
+                idx, alpha, s_t, targets, sums_all = pre[it]
+                if nstreams == 3:
+                    sc, sm = 0, 1 + it % 2
+                elif nstreams == 2:
+                    sc = sm = it % 2
+                else:
+                    sc = sm = 0
+                st_ = state[it]
+                masks = masks_of[it, lvl]
+                # a BatchNorm layer must see iteration 0's update first: only iteration 0's in-launch update is kept
+                # when iterations can overlap, later ones are queued for flush_bn_running()
+                E.defer_bn_running = E.bn_train and it >= 1 and nstreams > 1
+                with E.on(sc):
+                    cat = self.level_cross(lvl, skips[lvl], masks)
+                E.sync(sc, sm)
+                with E.on(sm):
+                    x, pred = self.level_main(lvl, cat, st_["x"], st_["pred"], mask_all[lvl], s_t, W, training, masks)
+                    L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None,
+                                                     L.ptr(sums_all[lvl * 8 * n:(lvl + 1) * 8 * n]), E.st()),
+                            "isa_mask_loss_sums")
+                st_["x"], st_["pred"] = x, pred
+                st_["preds"].append(pred)
                 if capture is not None:
                     capture["it%d.L%d.x" % (it, lvl)] = x
                     capture["it%d.L%d.pred" % (it, lvl)] = pred
+        E.defer_bn_running = False
+        for sid in forked:
+            E.sync(sid, 0)
+        E.flush_bn_running()
+        recs = [(state[it]["preds"], [pre[it][4][l * 8 * n:(l + 1) * 8 * n] for l in range(5)]) for it in range(max_iter)]
+        for it in range(max_iter):
+            idx, alpha, s_t, targets, sums_all = pre[it]
+            preds, sums = recs[it]
             coef, adv = E.f32(5 * 4 * n), E.f32(n)
             L.check(E.lib.isa_head_loss(L.ptr(sums_all), L.ptr(alpha), L.ptr(s_t), Lp, n, self._level_w, CE_WEIGHT,
                                         LAMBDA_L, LAMBDA_R, 1.0 / max_iter, L.ptr(self.baseline), 1 if training else 0,

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3, 4
 IN_1X1, IN_3X3, IN_GATHER2 = 0, 1, 2
 OUT_PLAIN, OUT_SHUFFLE2 = 0, 1
 
-_ERR = {-1: "ISA_EINVAL", -2: "ISA_EALIGN", -3: "ISA_EDTYPE", -4: "ISA_ELAUNCH"}
+_ERR = {-1: "ISA_EINVAL", -2: "ISA_EALIGN", -3: "ISA_EDTYPE", -4: "ISA_ELAUNCH", -5: "ISA_ENOMEM"}
 
 
 class IsaTensor(C.Structure):
@@ -35,6 +35,11 @@ class IsaBnBwd(C.Structure):
                 ("count", C.c_float), ("act", C.c_int32)]
 
 
+class IsaBnUpd(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("count", C.c_float), ("c", C.c_int32)]
+
+
 class IsaPackEntry(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("kind", C.c_int32),
                 ("n", C.c_int32), ("k", C.c_int32), ("taps", C.c_int32), ("kp", C.c_int32),
@@ -49,15 +54,18 @@ P_BN = C.POINTER(IsaBnBwd)
 SIGNATURES = {
     "isa_pack_weights": [VP, I32, VP, VP, VP, I32, VP],
     "isa_conv_gemm": [P_T, P_PRO, VP, I32, VP, P_T, I32, I32, VP, I32, VP],
-    "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP, I64, VP],
+    "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP, I64, VP, VP],
     "isa_colsum": [P_T, VP, VP],
     "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],
     "isa_dwconv3x3_dgrad": [P_T, VP, P_T, I32, VP],
-    "isa_dwconv3x3_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, VP, I64, VP],
-    "isa_dwconv3x3_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, I32, P_T, I32, P_T, VP, I64, VP],
-    "isa_conv1x1_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, P_T, I32, P_T, VP, I64, VP],
-    "isa_wgrad_defer_begin": [VP, I64],
-    "isa_wgrad_defer_flush": [VP, VP, VP],
+    "isa_dwconv3x3_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, VP, I64, VP, VP],
+    "isa_dwconv3x3_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, I32, P_T, I32, P_T, VP, I64, VP, VP],
+    "isa_conv1x1_bn_backward": [P_T, P_T, P_BN, P_T, P_PRO, P_BN, VP, VP, P_T, I32, P_T, VP, I64, VP, VP],
+    "isa_slab_arena_create": [VP, I64, C.POINTER(C.c_void_p)],
+    "isa_slab_arena_destroy": [VP],
+    "isa_slab_arena_begin": [VP],
+    "isa_slab_arena_flush": [VP, VP, VP, VP],
+    "isa_bn_running_update": [C.POINTER(IsaBnUpd), I32, F, VP],
     "isa_d4_augment": [VP, VP, I32, I32, I32, VP, VP],
     "isa_resize_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],
@@ -97,7 +105,7 @@ SIGNATURES = {
     "isa_se_bwd": [P_T, P_T, VP, VP, VP, VP, VP, I32, VP, VP, VP, VP, VP, VP, P_T, I32, VP],
     "isa_scale_bc": [P_T, VP, P_T, I32, VP],
     "isa_sqnorm": [VP, I64, F, VP, VP],
-    "isa_adadelta": [VP, VP, VP, VP, I64, F, F, F, F, VP, F, F, VP],
+    "isa_adadelta": [VP, VP, VP, VP, I64, F, F, F, F, VP, F, F, VP, VP],
     "isa_sdp_attention": [VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, VP],
     "isa_local_attention": [P_T, P_T, P_T, VP, P_T, I32, VP],
     "isa_point_query": [VP, P_T, VP, VP],

@@ -72,11 +72,23 @@ class Model(object):
         else:
             self.model.eval()
             with torch.no_grad():
-                sem_out, sem_arg, ins_cost, crit, ce, dice = self.model(False, images, sem, ins, n_objects.unsqueeze(1))
-            return {'INS Cost': ins_cost, 'Criterion': crit, 'ins_ce_loss': ce, 'ins_dice_loss': dice}
+                if self.use_instance_segmentation:
+                    sem_out, sem_arg, ins_cost, crit, ce, dice = self.model(False, images, sem, ins, n_objects.unsqueeze(1))
+                    row = {'INS Cost': ins_cost, 'Criterion': crit, 'ins_ce_loss': ce, 'ins_dice_loss': dice}
+                else:
+                    self.model(False, images)
+                    row = {}
+                if sem.dtype == torch.uint8:              # compact targets: one-hot on the device (isa_collate_targets)
+                    sem, _ = self.model.net.collate_targets(sem, ins)
+                costs = self.model.sem_costs(sem)         # the reference logs CE / Dice in validation too (model.py:255-269)
+                row['CE Cost'], row['Dice Cost'] = costs[0], costs[1]
+            return row
+        row = {'CE Cost': out['sem'][0].clone(), 'Dice Cost': out['sem'][1].clone()}
         h = out['head']
-        return {'INS Cost': h[0] + float('nan'), 'Criterion': h[1].clone(), 'ins_ce_loss': h[2].clone(),
-                'ins_dice_loss': h[3].clone(), 'CE Cost': out['sem'][0].clone(), 'Dice Cost': out['sem'][1].clone()}
+        if h is not None:                                 # semantic-only models have no instance head (model.py:244)
+            row.update({'INS Cost': h[0] + float('nan'), 'Criterion': h[1].clone(), 'ins_ce_loss': h[2].clone(),
+                        'ins_dice_loss': h[3].clone()})
+        return row
 
     def fit(self, criterion_type, delta_var, delta_dist, norm, learning_rate, weight_decay, clip_grad_norm,
             lr_drop_factor, lr_drop_patience, optimize_bg, optimizer, train_cnn, n_epochs, class_weights,

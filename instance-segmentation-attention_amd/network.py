@@ -112,7 +112,7 @@ class Network:
                 dy = E.grads.grad_of(sem)
                 L.check(E.lib.isa_conv_wgrad(gated.d(), gated.p(), dy.d(), P.gptr("sem_seg_output.weight"),
                                              P.gptr("sem_seg_output.bias"), L.IN_1X1, L.OUT_PLAIN, None, c,
-                                             L.ptr(E.ws), E.ws.numel(), E.st()),
+                                             L.ptr(E.ws), E.ws.numel(), E.defer_handle(), E.st()),
                         "isa_conv_wgrad(sem)")
                 dxa = E.new_act(n, x_dec.h, x_dec.w, c)
                 L.check(E.lib.isa_conv_gemm(dy.d(), None, E.packer.ptr(reg["dgrad"]), reg["kp_d"], None, dxa.d(),

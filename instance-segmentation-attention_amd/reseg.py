@@ -123,13 +123,13 @@ class ReSeg(nn.Module):
             self.store.int_buffers[name] = int(mod._buffers[leaf])
         self.engine.packer.table = None if self.engine.packer.entries else self.engine.packer.table
         self._weights_dirty = True
-        self.engine.eval_bn_cache.clear()
+        self.engine.eval_bn_stale = True
         return out
 
     def mark_weights_dirty(self):
         """Call after an optimizer step changed the flat parameter buffer (repack on next forward)."""
         self._weights_dirty = True
-        self.engine.eval_bn_cache.clear()
+        self.engine.eval_bn_stale = True
 
     # ------------------------------------------------------------------ hipGraph-replayed GT-free inference
     def infer_graphed(self, x):
@@ -145,7 +145,7 @@ class ReSeg(nn.Module):
         if slot is None:
             graphs[key] = dict(state="warm")
             with torch.no_grad():
-                return self.forward(False, x)
+                return self.forward(False, x, _arena_key=("infer_graph",) + key)
         if slot["state"] == "eager":
             with torch.no_grad():
                 return self.forward(False, x)
@@ -155,10 +155,13 @@ class ReSeg(nn.Module):
             if getattr(self, "_weights_dirty", True) and self.engine.packer.entries:
                 self.engine.packer.pack()                  # weights are constant across replays: pack outside
                 self._weights_dirty = False
+            if self.engine.eval_bn_stale:
+                self.engine.refresh_eval_bn()              # ... and so are the eval-mode BN constants
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"), torch.no_grad():
-                    out = self.forward(False, slot["x"])
+                    out = self.forward(False, slot["x"], _arena_key=("infer_graph",) + key)
+                self.engine.freeze_arena()
             except Exception as e:
                 import sys
                 print("[isa_amd] hipGraph capture failed (%s: %s); inference runs eagerly" % (type(e).__name__, e),
@@ -172,12 +175,29 @@ class ReSeg(nn.Module):
             if getattr(self, "_weights_dirty", False):     # parameters changed since capture: repack, then replay
                 self.engine.packer.pack()
                 self._weights_dirty = False
+            if self.engine.eval_bn_stale:                  # same buffers the graph reads, recomputed in place
+                self.engine.refresh_eval_bn()
             slot["x"].copy_(x, non_blocking=True)
         slot["graph"].replay()
         return slot["out"]
 
+    def sem_costs(self, sem_seg_target):
+        """Semantic CE + Dice(time=1) of the LAST forward's logits against a one-hot int64 target [B,2,H,W]
+        (validation branch of model.py:244-270).  Returns a device tensor [ce, dice]; must be called before the
+        next forward (the logits live in that step's arena)."""
+        sem = getattr(self, "_last_sem", None)
+        assert sem is not None, "sem_costs() follows a forward()"
+        t = sem_seg_target.to(self.store.device).contiguous()
+        assert t.dtype == torch.int64 and tuple(t.shape) == (sem.n, 2, sem.h, sem.w)
+        was = self.engine.record
+        self.engine.record = False
+        try:
+            return self.net.sem_loss(sem, t).clone()
+        finally:
+            self.engine.record = was
+
     # ------------------------------------------------------------------ forward
-    def forward(self, training, *_input, selected_idx=None, injected_s_t=None, capture=None):
+    def forward(self, training, *_input, selected_idx=None, injected_s_t=None, capture=None, _arena_key=None):
         """reseg.py:106-130.  (x) -> (sem_out, sem_argmax);  (x, sem_onehot[B,2,H,W] i64,
         ins[B,32,H,W] i64, N[B,1]) [or the compact uint8 pair sem[B,H,W], ins[B,H,W,32]: expanded on device] -> (sem_out, sem_argmax, ins_cost, criterion, ins_ce_loss,
         ins_dice_loss).  BatchNorm mode follows .train()/.eval() like the reference modules; the
@@ -198,7 +218,8 @@ class ReSeg(nn.Module):
             assert x.dim() == 4 and x.shape[1] == 21, "expects [B,21,H,W] (ImageEx tensor, utils.py:109)"
             assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
         dev = self.store.device
-        E.begin(bn_train=self.training, record=False)
+        E.begin(bn_train=self.training, record=False,
+                key=_arena_key or ("forward", has_gt, tuple(x.shape), x.dtype, bool(training)))
         if getattr(self, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         self._weights_dirty = False
@@ -207,6 +228,7 @@ class ReSeg(nn.Module):
         xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
         sem = net.sem_head(x_dec)
+        self._last_sem = sem                       # logits view in the step's arena (sem_costs)
         sem_out = net.to_nchw(sem)
         if has_gt:
             sem_argmax = sem_seg_target.to(dev).argmax(1).unsqueeze(1).float()

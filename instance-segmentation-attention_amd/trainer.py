@@ -23,11 +23,15 @@ class Trainer:
         self.sq = torch.zeros(n, dtype=torch.float32, device=st.device)       # Adadelta square_avg
         self.acc = torch.zeros(n, dtype=torch.float32, device=st.device)      # Adadelta acc_delta
         self.sqnorm = torch.zeros(4, dtype=torch.float32, device=st.device)
+        # the step size lives in a device scalar the optimizer kernel reads at run time: a captured hipGraph follows
+        # ReduceLROnPlateau (model.py:164,437) without re-capture
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=st.device)
+        self._lr_on_dev = float(lr)
         self.last = None
         self._graphs = {}
 
     def forward_backward(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, capture=None,
-                         idx_dev=None):
+                         idx_dev=None, arena_key=None):
         """Forward + backward; gradients land in model.store.grad.  Returns device scalars
         dict(sem=[ce, dice], head=[ins_cost_finite, criterion, ins_ce, ins_dice])."""
         m = self.model
@@ -37,7 +41,9 @@ class Trainer:
         sem = sem.to(dev).contiguous()
         ins = ins.to(dev).contiguous()
         st.grad[:st.n_train].zero_()
-        E.begin(bn_train=m.training, record=True)
+        E.begin(bn_train=m.training, record=True,
+                key=arena_key or ("train", tuple(x.shape), x.dtype, tuple(ins.shape), ins.dtype,
+                                  injected_s_t is not None))
         if getattr(m, "_weights_dirty", True) and E.packer.entries:
             E.packer.pack()
         m._weights_dirty = False
@@ -65,6 +71,12 @@ class Trainer:
         self.last = dict(sem=sem_scal, head=head_scal)
         return self.last
 
+    def sync_lr(self):
+        """Host lr -> device scalar (outside any graph; a no-op unless the scheduler changed it)."""
+        if self._lr_on_dev != float(self.lr):
+            self.lr_dev.fill_(float(self.lr))
+            self._lr_on_dev = float(self.lr)
+
     def apply_update(self):
         st = self.model.store
         n = st.n_train
@@ -74,12 +86,14 @@ class Trainer:
         if self.clip > 0:
             L.check(lib.isa_sqnorm(L.ptr(st.grad), n, gscale, L.ptr(self.sqnorm), L.stream_ptr()), "isa_sqnorm")
         L.check(lib.isa_adadelta(L.ptr(st.flat), L.ptr(st.grad), L.ptr(self.sq), L.ptr(self.acc), n, self.lr, self.rho,
-                                 self.eps, self.wd, L.ptr(self.sqnorm), float(self.clip), gscale, L.stream_ptr()),
+                                 self.eps, self.wd, L.ptr(self.sqnorm), float(self.clip), gscale, L.ptr(self.lr_dev),
+                                 L.stream_ptr()),
                 "isa_adadelta")
         self.model.mark_weights_dirty()
 
-    def train_step(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None):
-        out = self.forward_backward(x, sem, ins, n_objects, selected_idx, injected_s_t)
+    def train_step(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, arena_key=None):
+        self.sync_lr()
+        out = self.forward_backward(x, sem, ins, n_objects, selected_idx, injected_s_t, arena_key=arena_key)
         self.apply_update()
         return out
 
@@ -106,9 +120,12 @@ class Trainer:
         key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
                m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8, ins.dtype == torch.uint8)
         slot = self._graphs.get(key)
+        akey = ("train_graph",) + key            # the captured configuration owns its arena (frozen after capture)
+        self.sync_lr()
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")
-            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
+            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t,
+                                   arena_key=akey)
         if slot["state"] == "eager":
             return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
         if slot["state"] == "warm":
@@ -126,9 +143,10 @@ class Trainer:
                 # thread_local: the RCCL watchdog thread may query events while this thread captures
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
-                                                injected_s_t=slot["inj"])
+                                                injected_s_t=slot["inj"], arena_key=akey)
                     if self.world == 1:
                         self.apply_update()
+                m.engine.freeze_arena()
             except Exception as e:                 # capture refused (driver / collective state): stay eager, loudly
                 import sys
                 print("[isa_amd] hipGraph capture failed (%s: %s); this configuration runs eagerly" %

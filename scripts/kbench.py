@@ -45,11 +45,11 @@ def main(dtype=torch.bfloat16, which=None):
         tests = {
             "conv1x1": (lambda: lib.isa_conv_gemm(x.d(), None, eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
             "conv1x1+pro": (lambda: lib.isa_conv_gemm(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
-            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), 2),
-            "wgrad1x1_nopro": (lambda: lib.isa_conv_wgrad(x.d(), None, dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), 2),
+            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
+            "wgrad1x1_nopro": (lambda: lib.isa_conv_wgrad(x.d(), None, dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
             "dw+pro": (lambda: lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(regd["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), 2),
             "dw_dgrad": (lambda: lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(regd["dgrad"]), y.d(), 0, L.stream_ptr()), 2),
-            "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), 2),
+            "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
             "bn_bwd_reduce": (lambda: lib.isa_bn_bwd_reduce(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, L.ptr(red), L.stream_ptr()), 2),
             "bn_bwd_apply": (lambda: lib.isa_bn_bwd_apply(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, ps.ptr("bn.weight"), L.ptr(red), float(B * hw * hw), 1, y.d(), None, None, L.stream_ptr()), 3),
             "materialize+res": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), dy.d(), None, None, y.d(), L.stream_ptr()), 3),

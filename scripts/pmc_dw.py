@@ -16,5 +16,5 @@ reg = eng.reg_dw("wd"); eng.packer.pack()
 for _ in range(3):
     L.check(eng.lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), "dw")
     L.check(eng.lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(reg["dgrad"]), y.d(), 0, L.stream_ptr()), "dwd")
-    L.check(eng.lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), L.stream_ptr()), "dww")
+    L.check(eng.lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), "dww")
 torch.cuda.synchronize()

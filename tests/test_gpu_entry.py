@@ -52,3 +52,19 @@ def test_device_prefetcher_yields_the_same_batches_in_order():
             assert b.is_cuda and torch.equal(a, b.cpu())
         assert torch.equal(h[3], d[3]) and not d[3].is_cuda
     assert list(DevicePrefetcher([])) == []
+
+
+def test_fit_semantic_only_model(tmp_path):
+    """the reference trains and validates models without the instance head too (its default,
+    model.py:244-270, 426-435): CE / Dice are logged in both phases and drive the plateau scheduler."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import isa_amd  # noqa: F401
+    from isa_amd.model import Model
+    from isa_amd.data import SyntheticLoader
+    m = Model('CVPPP', 'ReSeg', 2, 32, use_instance_segmentation=False)
+    tr, te = SyntheticLoader(2, 2, 64, 64, seed=1), SyntheticLoader(1, 2, 64, 64, seed=2)
+    m.fit('Multi', 0.5, 1.5, 2, 1.0, 0.001, 10.0, 0.5, 25, False, 'Adadelta', True, 1, None, tr, te, str(tmp_path), False)
+    log = open(os.path.join(str(tmp_path), "validation.log")).read().strip().splitlines()
+    assert len(log) == 2 and 0.0 < float(log[1].split(",")[1]) < 1.5        # Dice Cost of the validation batch
+    assert [f for f in os.listdir(str(tmp_path)) if f.endswith(".pth")]

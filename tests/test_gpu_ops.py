@@ -312,43 +312,53 @@ def test_conv_backward(dtype, kind, cin, cout, hw):
     assert rel(dx.nchw(), xt.grad) < tol, "dX"
 
 
-def test_wgrad_defer_abi_contract():
-    """isa_wgrad_defer_begin/_flush argument checks and the empty pass; the numerics of deferred folds are covered by
-    every backward test above (Engine.backward defers by default) and by tests/test_gpu_train.py."""
+def test_slab_arena_abi_contract():
+    """isa_slab_arena_* argument checks, the empty pass, and exhaustion as an error code (never a silent fallback);
+    the numerics of deferred folds are covered by every backward test above (Engine.backward defers by default) and
+    by tests/test_gpu_train.py."""
     import ctypes as C
     L, Act, Engine, ParamStore, Pro = _gpu()
     lib = L.lib()
     st = L.stream_ptr()
     n, used = C.c_int32(-1), C.c_int64(-1)
-    assert lib.isa_wgrad_defer_flush(st, C.byref(n), C.byref(used)) != 0            # flush without begin
+    h = C.c_void_p()
     small = torch.empty(1 << 20, dtype=torch.float32, device="cuda")
-    assert lib.isa_wgrad_defer_begin(L.ptr(small), small.numel()) != 0              # arena below 16M floats
-    assert lib.isa_wgrad_defer_begin(None, 1 << 26) != 0
+    assert lib.isa_slab_arena_create(L.ptr(small), small.numel(), C.byref(h)) != 0       # region below 16M floats
+    assert lib.isa_slab_arena_create(None, 1 << 26, C.byref(h)) != 0
+    assert lib.isa_slab_arena_flush(None, st, C.byref(n), C.byref(used)) != 0            # no handle
     arena = torch.empty(17 << 20, dtype=torch.float32, device="cuda")
-    assert lib.isa_wgrad_defer_begin(L.ptr(arena), arena.numel()) == 0
-    assert lib.isa_wgrad_defer_flush(st, C.byref(n), C.byref(used)) == 0
+    assert lib.isa_slab_arena_create(L.ptr(arena), arena.numel(), C.byref(h)) == 0 and h.value
+    assert lib.isa_slab_arena_begin(h) == 0
+    assert lib.isa_slab_arena_flush(h, st, C.byref(n), C.byref(used)) == 0
     assert (n.value, used.value) == (0, 0)
-    assert lib.isa_wgrad_defer_flush(st, None, None) != 0                           # the pass is closed
-    # an arena with less than 64 MB left: the entry points fold immediately into dw (same result, nothing recorded)
+    assert lib.isa_slab_arena_destroy(h) == 0
+    # an arena with less than 64 MB left refuses the call with ISA_ENOMEM; with ISA_DEFER_FOLD off the entry points
+    # fold immediately from the caller's workspace (same result)
     w = rand(32, 32, 1, 1, seed=1)
     eng = make_engine(Engine, ParamStore, [("w", w.shape)], dict(w=w), torch.bfloat16)
     eng.fold_arena = torch.empty(16 << 20, dtype=torch.float32, device="cuda")     # exactly the minimum: usable once
-    for rep in range(2):
+    ref = None
+    for rep in range(3):
         eng.begin(bn_train=True, record=True)
         eng.params.grad.zero_()
         xa = to_act(Act, rand(2, 32, 16, 16, seed=3), torch.bfloat16)
         y1, y2 = eng.new_act(2, 16, 16, 32), eng.new_act(2, 16, 16, 32)
         eng.conv(xa, "w", y1)
-        eng.conv(xa, "w", y2)
-        for ya in (y1, y2):
+        if rep != 1:
+            eng.conv(xa, "w", y2)
+        for ya in ((y1, y2) if rep != 1 else (y1,)):
             g = eng.grads.grad_of(ya)
             g.buf.copy_(rand(2, 32, 16, 16, seed=5).permute(0, 2, 3, 1).to(g.buf.dtype))
             eng.grads.written[ya.buf.data_ptr()].append((0, 32))
-        eng.defer_fold = rep == 1
+        eng.defer_fold = rep != 0
+        if rep == 2:                                   # two weight-gradient calls, room for one
+            with pytest.raises(L.IsaError, match="ISA_ENOMEM"):
+                eng.backward()
+            continue
         eng.backward()
         torch.cuda.synchronize()
         if rep == 0:
-            ref = eng.params.gview("w").clone()
+            ref = eng.params.gview("w").clone()        # immediate folds, two convs
         else:
-            assert eng.fold_stats[0] == 1, eng.fold_stats          # the second conv found < 64 MB left: immediate fold
-            assert rel(eng.params.gview("w"), ref) < 1e-5
+            assert eng.fold_stats[0] == 1, eng.fold_stats
+            assert rel(2 * eng.params.gview("w"), ref) < 1e-5

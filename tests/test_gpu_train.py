@@ -233,13 +233,14 @@ def test_training_points_are_sampled_from_alpha():
 
 
 def test_deferred_weight_gradient_folds_match_immediate_folds():
-    """isa_wgrad_defer_begin/_flush: the same slabs folded at the end of the backward pass instead of after each
+    """isa_slab_arena_*: the same slabs folded at the end of the backward pass instead of after each
     layer; only the order of the fp32 atomic adds differs.  Two identical passes already differ by the order of the
     statistics atomics (amplified through the network), so the bound is that run-to-run noise, measured here."""
     ReSeg, Trainer = need_gpu()
     z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_f64.npz"))
     m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
     E = m.engine
+    m.head.streams = 1            # immediate folds share one workspace: single stream
     grads = []
     for mode in (False, False, True):
         E.defer_fold = mode
@@ -256,3 +257,122 @@ def test_deferred_weight_gradient_folds_match_immediate_folds():
     assert rel <= 3 * noise + 1e-5, (rel, noise)
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.9999, cos
+
+
+def _graph_fixture(dtype=torch.float32):
+    ReSeg, Trainer = need_gpu()
+    x, sem, ins, n = R.synth_batch(2, 64, 64, seed=1)
+    m = ReSeg(2, True, dtype=dtype)
+    m.load_state_dict(R.synth_state_dict(23, True))
+    m.train()
+    m.head.drop_rate = 0.0
+    m.head.sample_in_training = False
+    tr = Trainer(m)
+    inj = [torch.tensor([64 * 20 + 9, 64 * 41 + 30], dtype=torch.int32, device="cuda"),
+           torch.tensor([64 * 12 + 50, 64 * 33 + 17], dtype=torch.int32, device="cuda")]
+    order = [[0, 1], [1, 0]]
+    return m, tr, (x, sem, ins, n), order, inj
+
+
+def test_graph_survives_an_eval_forward_between_replays():
+    """Model.fit validates on the same engine between graphed training steps.  Every configuration
+    owns its arena and a captured one is frozen, so the eval forward can neither free nor reshape buffers the graph
+    points to; the replay after it must equal the eager step from the same restored state."""
+    m, tr, batch, order, inj = _graph_fixture()
+    for _ in range(2):                                                   # eager sight + capture
+        tr.train_step_graphed(*batch, selected_idx=order, injected_s_t=inj)
+    torch.cuda.synchronize()
+    assert any(s.get("state") == "ready" for s in tr._graphs.values())
+    snap = _snapshot(m, tr)
+    x, sem, ins, n = batch
+    m.eval()
+    with torch.no_grad():
+        m(False, x, sem, ins, n.view(-1, 1))                             # validation forward: other arena
+        m(False, x[:1].contiguous(), sem[:1], ins[:1], n[:1].view(-1, 1))   # and another batch size
+    junk = [torch.full((1 << 24,), float("nan"), device="cuda") for _ in range(4)]   # would land in freed arena blocks
+    del junk
+    m.train()
+    _restore(m, tr, snap)
+    tr.train_step_graphed(*batch, selected_idx=order, injected_s_t=inj)
+    torch.cuda.synchronize()
+    g_graph, p_graph = m.store.grad.clone(), m.store.flat.clone()
+    _restore(m, tr, snap)
+    tr.train_step(*batch, selected_idx=order, injected_s_t=inj)
+    torch.cuda.synchronize()
+    g_eager, p_eager = m.store.grad.clone(), m.store.flat.clone()
+    assert torch.isfinite(g_graph).all() and torch.isfinite(p_graph).all()
+    cos = float(torch.nn.functional.cosine_similarity(g_graph.double(), g_eager.double(), dim=0))
+    assert cos > 0.9995, cos
+    assert float((p_graph - p_eager).abs().max()) < 2e-2
+    # the frozen arena refuses a diverging allocation sequence instead of freeing captured buffers
+    frozen = [a for a in m.engine.arenas.values() if a.frozen]
+    assert len(frozen) == 1
+    arena = frozen[0]
+    arena.reset()
+    with pytest.raises(RuntimeError, match="captured hipGraph"):
+        arena.alloc((3, 5, 7), torch.float32)
+
+
+def test_learning_rate_change_reaches_the_captured_graph():
+    """ReduceLROnPlateau halves Trainer.lr between epochs (model.py:164,437); the optimizer kernel
+    reads the step size from a device scalar, so a replay must move the parameters exactly half as far as before
+    and agree with the eager step at the reduced rate."""
+    m, tr, batch, order, inj = _graph_fixture()
+    for _ in range(2):
+        tr.train_step_graphed(*batch, selected_idx=order, injected_s_t=inj)
+    torch.cuda.synchronize()
+    snap = _snapshot(m, tr)
+
+    def delta(step, lr):
+        _restore(m, tr, snap)
+        tr.lr = lr
+        before = m.store.flat[:m.store.n_train].clone()
+        step(*batch, selected_idx=order, injected_s_t=inj)
+        torch.cuda.synchronize()
+        return (m.store.flat[:m.store.n_train] - before).double()
+
+    d_full, d_half = delta(tr.train_step_graphed, 1.0), delta(tr.train_step_graphed, 0.5)
+    e_half = delta(tr.train_step, 0.5)
+    assert float(d_full.norm()) > 0
+    ratio = float(d_half.norm() / d_full.norm())
+    assert abs(ratio - 0.5) < 2e-2, ratio                # Adadelta's update is linear in lr
+    assert float((d_half - e_half).norm() / e_half.norm()) < 5e-2
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_concurrent_streams_match_the_sequential_pass(streams):
+    """The decoder iterations (and their cross chains) run on separate HIP streams; what the reference's sequential
+    loop (attenet2.py:384-399) guaranteed implicitly is restored explicitly: ordered BatchNorm running-statistics
+    updates (isa_bn_running_update), per-stream gradients of the shared backbone features merged after the join,
+    loss assembly in iteration order.  Everything must equal the single-stream pass up to float-atomic order."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_f64.npz"))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run(ns):
+        m.load_state_dict(state0)
+        m.head.baseline = None
+        m.head.streams = ns
+        cap = {}
+        out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj, capture=cap)
+        torch.cuda.synchronize()
+        acts = {k: v.nchw().clone() for k, v in cap.items() if k.startswith("it")}
+        sd = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        return m.store.grad.double().clone(), acts, sd, [float(v) for v in out["head"][1:]], float(m.head.baseline)
+
+    g1, a1, s1, h1, b1 = run(1)
+    g1b = run(1)[0]
+    gN, aN, sN, hN, bN = run(streams)
+    noise = float((g1 - g1b).norm() / g1.norm())
+    assert float((g1 - gN).norm() / g1.norm()) <= 3 * noise + 1e-5, (noise, float((g1 - gN).norm() / g1.norm()))
+    for k in a1:
+        assert float((a1[k] - aN[k]).abs().max()) <= 1e-4 * max(1.0, float(a1[k].abs().max())), k
+    for k in s1:
+        if "num_batches" in k:
+            assert int(s1[k]) == int(sN[k]), k
+        else:
+            assert float((s1[k] - sN[k]).abs().max()) <= 1e-5 * max(1.0, float(s1[k].abs().max())), k
+    for u, v in zip(h1, hN):
+        assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
+    assert abs(b1 - bN) <= 1e-6 * max(1.0, abs(b1))
