@@ -176,6 +176,8 @@ class ParamStore:
                 off += rup(numel, 4)          # keep every tensor 16-byte aligned
             if k == 0:
                 self.n_train = off
+            if k == 1:
+                self.buffer_start = off       # float buffers (BN running statistics) start here
         for n, _ in schema:
             if klass(n) == 3:
                 self.int_buffers[n] = 0

@@ -9,6 +9,7 @@ import os
 import numpy as np
 import torch
 
+from . import parallel
 from .reseg import ReSeg
 from .trainer import Trainer
 
@@ -25,6 +26,8 @@ class Model(object):
         assert self.model_name in ['ReSeg', 'StackedRecurrentHourglass']      # model.py:40
         assert self.model_name == 'ReSeg', "only ReSeg is live at HEAD (SURVEY.md §0-2)"
         assert usegpu, "this build has no CPU path"
+        # data parallel: one process per GPU under torch.distributed.run; a single process otherwise (parallel.py)
+        self.world, self.rank, self.local_rank = parallel.env_world()
         self.model = ReSeg(self.n_classes, self.use_instance_segmentation, pretrained=True,
                            use_coordinates=self.use_coords, use_wae=use_wae, usegpu=True, dtype=dtype)
         self.__load_weights()
@@ -46,7 +49,7 @@ class Model(object):
                            optimizer='Adadelta'):
         assert optimizer in ['RMSprop', 'Adam', 'Adadelta', 'SGD']            # model.py:147
         assert optimizer == 'Adadelta', "the shipped TrainingSettings use Adadelta (training_settings.py:27)"
-        self.trainer = Trainer(self.model, lr=learning_rate, weight_decay=weight_decay,
+        self.trainer = Trainer(self.model, world_size=self.world, lr=learning_rate, weight_decay=weight_decay,
                                clip_grad_norm=clip_grad_norm)
         self._plateau = dict(best=float('inf'), bad=0, factor=lr_drop_factor, patience=lr_drop_patience)
 
@@ -59,7 +62,8 @@ class Model(object):
         if p['bad'] > p['patience']:
             self.trainer.lr *= p['factor']
             p['bad'] = 0
-            print('Reducing learning rate to {}'.format(self.trainer.lr))
+            if self.rank == 0:
+                print('Reducing learning rate to {}'.format(self.trainer.lr))
 
     def __minibatch(self, batch, mode):
         assert mode in ['training', 'test'], 'Mode must be either "training" or "test"'      # model.py:193
@@ -94,10 +98,13 @@ class Model(object):
             lr_drop_factor, lr_drop_patience, optimize_bg, optimizer, train_cnn, n_epochs, class_weights,
             train_loader, test_loader, model_save_path, debug):
         assert criterion_type in ['CE', 'Dice', 'Multi']                       # model.py:364
-        os.makedirs(model_save_path, exist_ok=True)
-        tlog = open(os.path.join(model_save_path, 'training.log'), 'w')
-        vlog = open(os.path.join(model_save_path, 'validation.log'), 'w')
-        tlog.write('Epoch,Cost\n'); vlog.write('Epoch,Cost\n')
+        main = self.rank == 0                   # only rank 0 writes logs and checkpoints (parallel.py: policy)
+        tlog = vlog = None
+        if main:
+            os.makedirs(model_save_path, exist_ok=True)
+            tlog = open(os.path.join(model_save_path, 'training.log'), 'w')
+            vlog = open(os.path.join(model_save_path, 'validation.log'), 'w')
+            tlog.write('Epoch,Cost\n'); vlog.write('Epoch,Cost\n')
         self.__define_optimizer(learning_rate, weight_decay, lr_drop_factor, lr_drop_patience, clip_grad_norm, optimizer)
         best_val_cost = np.inf
         if os.environ.get('ISA_PREFETCH', '1') != '0':      # batch i+1 uploads on a side stream while step i runs
@@ -105,19 +112,28 @@ class Model(object):
             train_loader, test_loader = DevicePrefetcher(train_loader), DevicePrefetcher(test_loader)
         for epoch in range(n_epochs):
             tr = [self.__minibatch(b, 'training') for b in train_loader]
+            # every rank validates the same model: average the per-rank running estimates first
+            parallel.sync_buffers(self.model.store, self.model.head.baseline if self.use_instance_segmentation else None,
+                                  self.world)
             va = [self.__minibatch(b, 'test') for b in test_loader]
             mean = lambda rows, k: float(torch.stack([r[k].float() for r in rows]).mean())
             key = 'ins_dice_loss' if self.use_instance_segmentation else 'Dice Cost'
-            train_cost, val_cost = mean(tr, key), mean(va, key)
-            print('Epoch : [{}/{}]  train {} {:.5f} | val {:.5f}'.format(epoch, n_epochs, key, train_cost, val_cost))
+            # rank-averaged costs: the plateau scheduler must take the same decision on every rank
+            train_cost = parallel.mean_over_ranks(mean(tr, key), self.world)
+            val_cost = parallel.mean_over_ranks(mean(va, key), self.world)
+            if main:
+                print('Epoch : [{}/{}]  train {} {:.5f} | val {:.5f}'.format(epoch, n_epochs, key, train_cost, val_cost))
             self.__plateau_step(val_cost)
             if val_cost <= best_val_cost:                                       # model.py:439-446
                 best_val_cost = val_cost
-                torch.save(self.model.state_dict(), os.path.join(
-                    model_save_path, 'model_{}_{}_{}.pth'.format(epoch, val_cost, self.trainer.lr)))
-            tlog.write('{},{}\n'.format(epoch, train_cost)); vlog.write('{},{}\n'.format(epoch, val_cost))
-            tlog.flush(); vlog.flush()
-        tlog.close(); vlog.close()
+                if main:
+                    torch.save(self.model.state_dict(), os.path.join(
+                        model_save_path, 'model_{}_{}_{}.pth'.format(epoch, val_cost, self.trainer.lr)))
+            if main:
+                tlog.write('{},{}\n'.format(epoch, train_cost)); vlog.write('{},{}\n'.format(epoch, val_cost))
+                tlog.flush(); vlog.flush()
+        if main:
+            tlog.close(); vlog.close()
 
     # ------------------------------------------------------------------ inference (model.py:466-499)
     def predict(self, images):

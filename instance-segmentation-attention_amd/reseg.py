@@ -227,6 +227,9 @@ class ReSeg(nn.Module):
             sem_seg_target, ins_seg_target = net.collate_targets(sem_seg_target, ins_seg_target)
         xin = net.input_view(x)
         x_dec, feats = net.unet(xin)
+        if capture is not None:                    # UNet.forward's six maps (unet_model.py:36), for parity tests
+            capture.update({"unet.x_dec": x_dec, "unet.x1": feats[0], "unet.x2": feats[1], "unet.x3": feats[2],
+                            "unet.x4": feats[3], "unet.x5": feats[4]})
         sem = net.sem_head(x_dec)
         self._last_sem = sem                       # logits view in the step's arena (sem_costs)
         sem_out = net.to_nchw(sem)

@@ -10,7 +10,7 @@ import random
 import torch
 
 from . import lib as L
-from .parallel import allreduce_flat_
+from .parallel import exchange_and_update
 
 
 class Trainer:
@@ -27,6 +27,10 @@ class Trainer:
         # ReduceLROnPlateau (model.py:164,437) without re-capture
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=st.device)
         self._lr_on_dev = float(lr)
+        if world_size > 1:          # identical start on every rank (checkpoints are loaded per process)
+            import torch.distributed as dist
+            dist.broadcast(st.flat, src=0)
+            model.mark_weights_dirty()
         self.last = None
         self._graphs = {}
 
@@ -78,17 +82,21 @@ class Trainer:
             self._lr_on_dev = float(self.lr)
 
     def apply_update(self):
+        """all-reduce (world > 1) -> norm of the averaged gradient -> clip + Adadelta: parallel.exchange_and_update
+        owns the ordering (the CPU test drives the same function with stand-in kernels)."""
         st = self.model.store
-        n = st.n_train
-        gscale = allreduce_flat_(st.grad, n, self.world)     # one flat RCCL all-reduce (sum)
         lib = self.model.engine.lib
         self.sqnorm.zero_()
-        if self.clip > 0:
-            L.check(lib.isa_sqnorm(L.ptr(st.grad), n, gscale, L.ptr(self.sqnorm), L.stream_ptr()), "isa_sqnorm")
-        L.check(lib.isa_adadelta(L.ptr(st.flat), L.ptr(st.grad), L.ptr(self.sq), L.ptr(self.acc), n, self.lr, self.rho,
-                                 self.eps, self.wd, L.ptr(self.sqnorm), float(self.clip), gscale, L.ptr(self.lr_dev),
-                                 L.stream_ptr()),
-                "isa_adadelta")
+
+        def sqnorm_fn(grad, n, gscale):
+            L.check(lib.isa_sqnorm(L.ptr(grad), n, gscale, L.ptr(self.sqnorm), L.stream_ptr()), "isa_sqnorm")
+
+        def update_fn(grad, n, gscale):
+            L.check(lib.isa_adadelta(L.ptr(st.flat), L.ptr(grad), L.ptr(self.sq), L.ptr(self.acc), n, self.lr, self.rho,
+                                     self.eps, self.wd, L.ptr(self.sqnorm), float(self.clip), gscale, L.ptr(self.lr_dev),
+                                     L.stream_ptr()), "isa_adadelta")
+
+        exchange_and_update(st.grad, st.n_train, self.world, sqnorm_fn, update_fn, self.clip)
         self.model.mark_weights_dirty()
 
     def train_step(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, arena_key=None):

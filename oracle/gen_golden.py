@@ -217,12 +217,18 @@ def main():
         ("train_64", 64, 2, "train", torch.float32),
         ("train_64_f64", 64, 2, "train", torch.float64),
         ("train_256", 256, 2, "train", torch.float32),
+        ("train_256_f64", 256, 2, "train", torch.float64),     # the reference's own fp64 run: gradient floor at 256^2
     ]
+    only = set(sys.argv[1:])              # python oracle/gen_golden.py [case ...]: regenerate a subset
     for name, size, batch, mode, dtype in cases:
+        if only and name not in only:
+            continue
         st = run_case(reseg, config, name, size, batch, mode, dtype)
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **st)
         print(name, len(st), "arrays", os.path.getsize(path) // 1024, "KiB")
+    if only and "byname_ops" not in only:
+        return
     st = {}
     byname_cases(st)
     path = os.path.join(OUT, "byname_ops.npz")

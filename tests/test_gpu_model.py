@@ -81,20 +81,37 @@ def test_inference_vs_reference_golden(case):
         m2(False, x)
 
 
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def margin_iou(l16, l32, t):
+    """IoU of the thresholded masks over the pixels whose fp32 margin |l1 - l0| exceeds 2 * t * max|logit|: a logit
+    error below t * max|logit| cannot flip them.  Returns (iou, fraction of pixels kept, raw iou over all pixels)."""
+    keep = ((l32[:, 1] - l32[:, 0]).abs() > 2 * t * float(l32.abs().max())).numpy()
+    m16, m32 = (l16[:, 1] > l16[:, 0]).numpy(), (l32[:, 1] > l32[:, 0]).numpy()
+    return iou(m16[keep], m32[keep]), float(keep.mean()), iou(m16, m32)
+
+
 def test_inference_bf16_mask_iou():
+    """bf16 storage against the fp32 oracle (the reference's algorithm on the CPU) at 256x256.  Raw conv outputs are
+    rounded to bf16 BEFORE BatchNorm (as under torch autocast), so a channel whose mean is large against its spread
+    carries a relative error of 2^-9 * |mean| / std after normalisation; at random init that accumulates to a few per
+    cent of the logit scale (measured: DESIGN.md 2).  Bounds: relative L2 of the logits, and the thresholded mask
+    identical (IoU >= 0.999) on every pixel whose oracle margin exceeds 10 % of the logit scale."""
     ReSeg = need_gpu()
     x, _, _, _ = R.synth_batch(2, 256, 256, seed=1)
     m, sd = build(ReSeg, False, torch.bfloat16, False)
     sem_out, sem_arg = m(False, x)
     with torch.no_grad():
-        ref = R.reseg_forward(sd, x, use_instance_seg=False)
-    mine = torch.softmax(sem_out.cpu(), 1)[:, 1] > 0.5
-    want = torch.softmax(ref["sem_out"], 1)[:, 1] > 0.5
-    # random-init logits hover around 0, the hardest case for a thresholded mask; a trained net sits
-    # far from the threshold.  Recorded, with a floor that catches real breakage.
-    v = iou(mine.numpy(), want.numpy())
-    print("bf16 sem mask IoU vs fp32 oracle: %.4f" % v)
-    assert v > 0.90
+        ref = R.reseg_forward(sd, x, use_instance_seg=False)["sem_out"]
+    got = sem_out.cpu()
+    l2, mx = _rel_l2(got, ref), float((got - ref).abs().max() / ref.abs().max())
+    v, kept, raw = margin_iou(got, ref, 0.05)
+    print("bf16 sem logits vs fp32 oracle: rel-L2 %.3e, max-abs/max %.3e; IoU %.5f on the %.1f%% confident pixels; raw IoU %.4f"
+          % (l2, mx, v, 100 * kept, raw))
+    assert l2 <= 0.10 and mx <= 0.30, (l2, mx)
+    assert v >= 0.999 and kept > 0.3, (v, kept)
 
 
 def _run_gt(ReSeg, z, dtype, training):
@@ -120,12 +137,32 @@ def test_forward_with_gt_vs_reference_golden(case, training):
     for nm, key in (("x_enc", "x_enc"), ("s_sp.out", "s_sp")):
         err, _ = G.compare(z, nm, cap[key].nchw().cpu().numpy())
         assert err < tol, (nm, err)
+    for nm in ("x_dec", "x1", "x2", "x3", "x4", "x5"):                 # UNet.forward's six maps (unet_model.py:36)
+        err, cs = G.compare(z, "unet." + nm, cap["unet." + nm].nchw().cpu().numpy())
+        assert err < tol and cs < tol, (nm, err, cs)
     size = int(z["meta/size_batch_seed"][0])
     b = int(z["meta/size_batch_seed"][1])
     err, _ = G.compare(z, "attend.pro_merge", cap["merge"].view(b, 1, size, size).cpu().numpy())
     assert err < tol, err
     rec = m.last_record
     assert len(rec["iters"]) == z["inject/s_t"].shape[0]
+    # alpha (utils.py:648-655): the reference evaluates pro_split[B,32,H,W]; here only the row of the instance each
+    # iteration selects exists.  Compare those rows, as floats, at the fixture's stored sample positions.
+    shape = tuple(int(v) for v in z["attend.pro_split/shape"])
+    total = int(np.prod(shape))
+    pos = np.arange(0, total, G.subsample_stride(total))
+    ref = z["attend.pro_split/sub"].astype(np.float64)
+    pb, pi, ppix = pos // (shape[1] * size * size), (pos // (size * size)) % shape[1], pos % (size * size)
+    checked = 0
+    for r in rec["iters"]:
+        idx = r["idx"].cpu().numpy()
+        alpha = r["alpha"].view(b, -1).cpu().numpy().astype(np.float64)
+        selm = pi == idx[pb]
+        checked += int(selm.sum())
+        got = alpha[pb[selm], ppix[selm]]
+        assert np.abs(got - ref[selm]).max() <= tol * max(np.abs(ref[selm]).max(), 1e-30), "alpha rows"
+        assert abs(alpha.sum() - b) < 1e-3                              # each selected row is a distribution
+    assert checked > 50, checked
     for it, r in enumerate(rec["iters"]):
         assert r["s_t"].cpu().tolist() == [int(v) for v in z["inject/s_t"][it]]          # exact
         for lvl in range(5):
@@ -161,18 +198,55 @@ def test_forward_with_gt_vs_reference_golden(case, training):
         assert int(sd_after["decoder.attend.bn.num_batches_tracked"]) == nbt[2]
 
 
-def test_train_forward_256_bf16_scalars_and_iou():
+def test_train_forward_256_bf16_per_level_bounds_and_margin_aware_iou():
+    """bf16 storage (the benchmarked precision) at 256x256 against (a) the reference's own outputs (train_256.npz:
+    loss scalars, mask bits) and (b) the fp32-storage run of the same HIP path (itself within 1e-3 of the reference:
+    the tests above), which supplies the full-resolution logits the fixture only samples.
+      * loss scalars within 1e-2 of the reference's (measured 3e-3);
+      * per tensor relative-L2 error of the six UNet maps, x_enc and every level's x / pred (2 iterations x 5 levels):
+        bounds at ~1.5x the measured values (scripts/bf16diag.py: UNet 0.7 - 2.4 %, x_enc 4.7 %, decoder levels 8 - 13 %;
+        bf16 rounds the raw conv outputs ahead of BatchNorm, see test_inference_bf16_mask_iou);
+      * margin-aware IoU: on the pixels whose fp32 margin |l1 - l0| exceeds 10 % of max|logit| (4 % for the
+        semantic head) the bf16 mask equals the fp32 mask AND the reference's stored bits (IoU >= 0.999), for the
+        semantic mask and all ten instance masks; the fraction of pixels kept and the raw IoU are printed."""
     ReSeg = need_gpu()
     z = load("train_256")
+    m32, out32, cap32 = _run_gt(ReSeg, z, torch.float32, True)
+    acts32 = {k: v.nchw().cpu() for k, v in cap32.items() if k.startswith(("it", "unet.")) or k == "x_enc"}
+    sem32 = out32[0].cpu()
+    del m32, cap32
     m, out, cap = _run_gt(ReSeg, z, torch.bfloat16, True)
     vals = dict(zip(("ins_cost", "criterion", "ins_ce_loss", "ins_dice_loss"), out[2:]))
     for k in ("criterion", "ins_ce_loss", "ins_dice_loss"):
         ref = float(z["scalars/" + k][0])
-        assert abs(float(vals[k]) - ref) <= 5e-2 * max(1.0, abs(ref)), (k, float(vals[k]), ref)
-    pred = cap["it1.L4.pred"].nchw().cpu()
-    v = iou((pred[:, 1] > pred[:, 0]).numpy(), G.unpack_bits(z, "it1.L4.mask_pred"))
-    print("bf16 instance-mask IoU (level 4, iter 1) vs fp32 reference: %.4f" % v)
-    assert v > 0.5
+        assert abs(float(vals[k]) - ref) <= 1e-2 * max(1.0, abs(ref)), (k, float(vals[k]), ref)
+    worst = {}
+    for k, a32 in sorted(acts32.items()):
+        a16 = cap[k].nchw().cpu()
+        grp = "unet" if k.startswith("unet.") else ("x_enc" if k == "x_enc" else "decoder")
+        bound = dict(unet=4e-2, x_enc=8e-2, decoder=0.2)[grp]
+        e = _rel_l2(a16, a32)
+        worst[grp] = max(worst.get(grp, 0.0), e)
+        assert e <= bound, (k, e, bound)
+        assert float((a16 - a32).abs().max() / a32.abs().max()) <= 2 * bound, k
+    print("bf16 vs fp32 storage at 256x256, worst relative-L2 per group:", {k: "%.3e" % v for k, v in worst.items()})
+
+    def check_mask(l16, l32, bits_ref, name, t):
+        v, kept, raw = margin_iou(l16, l32, t)
+        keep = ((l32[:, 1] - l32[:, 0]).abs() > 2 * t * float(l32.abs().max())).numpy()
+        vr = iou((l16[:, 1] > l16[:, 0]).numpy()[keep], np.asarray(bits_ref, bool)[keep])
+        print("%-8s kept %5.1f%% of the pixels; IoU on them %.5f (vs the reference's bits %.5f); raw IoU %.4f"
+              % (name, 100.0 * kept, v, vr, raw))
+        assert v >= 0.999 and vr >= 0.999, (name, v, vr)
+        assert kept > 0.3, (name, kept)
+
+    sem16 = out[0].cpu()
+    assert _rel_l2(sem16, sem32) <= 5e-2
+    check_mask(sem16, sem32, (sem32[:, 1] > sem32[:, 0]).numpy(), "sem", 0.02)
+    for it in range(2):
+        for lvl in range(5):
+            pre = "it%d.L%d" % (it, lvl)
+            check_mask(cap[pre + ".pred"].nchw().cpu(), acts32[pre + ".pred"], G.unpack_bits(z, pre + ".mask_pred"), pre, 0.05)
 
 
 def test_graph_replayed_inference_matches_eager():

