@@ -114,7 +114,9 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 // instantiated for {RELU6, LEAKY where the prediction heads use it, runtime}.
 constexpr int ACT_RT = -1;
 template <int ACT> __device__ __forceinline__ float act_t(float z, int rt) {
-    if constexpr (ACT == ISA_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
+    // v_med3_f32: one instruction for the clamp (fminf(fmaxf()) compiles to v_max + v_min); same result for every
+    // input including NaN (-> 0, as fmaxf(NaN, 0) = 0)
+    if constexpr (ACT == ISA_ACT_RELU6) return __builtin_amdgcn_fmed3f(z, 0.f, 6.f);
     else if constexpr (ACT == ISA_ACT_NONE) return z;
     else if constexpr (ACT == ISA_ACT_LEAKY) return z > 0.f ? z : 0.01f * z;
     else return act_apply(z, rt);

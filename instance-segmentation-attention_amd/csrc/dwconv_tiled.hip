@@ -124,19 +124,45 @@ __device__ __forceinline__ TileRange tile_range(long ntiles) {
     return TileRange{(long)blockIdx.x, ntiles, (long)G};
 }
 
+// Tile coordinates kept incrementally: the tile sequence of a workgroup is t0, t0 + step, ... and a 64-bit
+// `t % tiles_x`, `t / tiles_x % tiles_y` pair per tile per role cost more scalar instructions than the tile's loads
+// (ablation: with every load, LDS access, FMA and store removed the forward kernel still took 39 of its 93 us - the
+// per-tile bookkeeping; one wave per role and SIMD issues an instruction every >= 4 cycles).  All fields are
+// wave-uniform (SGPRs).
+struct TileIter {
+    long t, end, step;
+    int tx, ty, b, sx, sy, sb, ntx, nty;
+    __device__ __forceinline__ void init(const TileRange& r, int tiles_x, int tiles_y) {
+        t = r.t0; end = r.end; step = r.step; ntx = tiles_x; nty = tiles_y;
+        long q = t / tiles_x; tx = (int)(t - q * tiles_x); b = (int)(q / tiles_y); ty = (int)(q - (long)b * tiles_y);
+        long qs = step / tiles_x; sx = (int)(step - qs * tiles_x); sb = (int)(qs / tiles_y); sy = (int)(qs - (long)sb * tiles_y);
+    }
+    __device__ __forceinline__ bool valid() const { return t < end; }
+    __device__ __forceinline__ void next() {
+        t += step;
+        tx += sx; const int c = tx >= ntx ? 1 : 0; tx -= c * ntx;
+        ty += sy + c; const int c2 = ty >= nty ? 1 : 0; ty -= c2 * nty;
+        b += sb + c2;
+    }
+};
+
 // Persistent over tiles of one channel block.  DB (bf16): 512 threads, waves 4-7 stage the next tile into the other
 // LDS buffer while waves 0-3 run the stencil on the current one (the same role split as dw_bn_bwd_kernel below);
 // weights, prologue constants and the statistic partial sums live across tiles and are flushed once.
 template <typename T, bool HAS_PRO, int ACT, bool DB>
-__global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 3))) void dw2_fwd_kernel(Dw2Params p) {
-    constexpr int NTHR = DB ? 512 : 256;
+__global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(2, 3))) void dw2_fwd_kernel(Dw2Params p) {
+    // DB: waves 0-3 compute, waves 4-11 stage (three waves per SIMD: the staging arithmetic of a tile is spread over
+    // twice the lanes and the SIMD has one more wave to issue from while the others wait)
+    constexpr int NTHR = DB ? 768 : 256;
+    constexpr int LTHR = DB ? 512 : 256;              // threads that stage a tile
     constexpr int NBUF = DB ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* tile_base = sm;                          // [NBUF][HALO][PS]
     float* wts = sm + NBUF * HALO * PS;             // [9][CB]
     float* red = wts + 9 * CB;                      // [2*CB]
-    const int tid = threadIdx.x, ltid = tid & 255;
+    const int tid = threadIdx.x;
     const bool loader = DB && tid >= 256;
+    const int ltid = loader ? tid - 256 : tid;        // index inside the role group
     const int c_base = blockIdx.y * CB;
     const T* wp = reinterpret_cast<const T*>(p.w);
     for (int i = tid; i < 9 * CB; i += NTHR) {
@@ -148,7 +174,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const int c0 = c_base + cg * 8;
     const bool cok = c0 < p.c;
     const T* xin = reinterpret_cast<const T*>(p.x);
-    constexpr int NIT = (HALO * 4 + 255) / 256;
+    constexpr int NIT = (HALO * 4 + LTHR - 1) / LTHR;
 
     // per-channel prologue constants: loaded ONCE per lane (they were re-read from global memory at the top of every
     // tile: a dependent round trip ahead of the tile's own loads); only the per-image scale changes with the tile
@@ -159,60 +185,88 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
         sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
     }
-    auto stage = [&](long t, float* tile) {
-        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
-        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+    // tile-invariant part of the staging addresses: halo pixel (rr, cc) of slot `it` and its element offset from the
+    // tile's halo origin; per tile only a scalar base pointer and (on border tiles) four scalar bounds remain
+    int hrc[NIT], hoff[NIT];
+    bool hok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pix = (ltid + it * LTHR) >> 2;
+        const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+        hrc[it] = (rr << 16) | cc;
+        hoff[it] = (rr * p.w_ + cc) * p.ldx + (cok ? c0 : c_base);
+        hok[it] = pix < HALO && cok;
+    }
+    const int ooff = (row * p.w_ + x0) * p.ldy + c0;           // output element offset from the tile's origin
+
+    auto stage = [&](int b, int ty, int tx, float* tile) {
         float bs[8];
+        if (HAS_PRO && p.pro.bscale) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            bs[j] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale[(long)b * p.c + min(c0 + j, p.c - 1)] : 1.f;
-        raw8<T> v[NIT]; bool ok[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int pix = (ltid + it * 256) >> 2;
-            const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
-            const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
-            ok[it] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
-            if (ok[it]) v[it].load(xin + (((long)b * p.h + gy) * p.w_ + gx) * p.ldx + c0);
+            for (int j = 0; j < 8; ++j) bs[j] = p.pro.bscale[(long)b * p.c + min(c0 + j, p.c - 1)];
         }
+        const T* base = xin + (((long)b * p.h + ty * TH - 1) * p.w_ + tx * TW - 1) * p.ldx;   // halo origin (may lie outside)
+        // scalar bounds of the in-image part of the halo, in halo coordinates
+        const int rlo = 1 - ty * TH, rhi = p.h + 1 - ty * TH, clo = 1 - tx * TW, chi = p.w_ + 1 - tx * TW;
+        const bool interior = rlo <= 0 && rhi >= TH + 2 && clo <= 0 && chi >= TW + 2;
+        raw8<T> v[NIT]; bool ok[NIT];
+        if (interior) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) { ok[it] = hok[it]; if (ok[it]) v[it].load(base + hoff[it]); }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rr = hrc[it] >> 16, cc = hrc[it] & 0xffff;
+                ok[it] = hok[it] && rr >= rlo && rr < rhi && cc >= clo && cc < chi;
+                if (ok[it]) v[it].load(base + hoff[it]);
+            }
+        }
+        const bool has_bs = HAS_PRO && p.pro.bscale;             // wave-uniform: hoisted out of the element loops
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int pix = (ltid + it * 256) >> 2;
+            const int pix = (ltid + it * LTHR) >> 2;
             if (pix >= HALO) continue;
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float z = 0.f;
-                if (ok[it]) {
-                    z = v[it].get(j);
-                    if constexpr (HAS_PRO) {
-                        z = act_t<ACT>(fmaf(z, sc[j], sh[j]), p.pro.act);
-                        if (p.pro.bscale) z *= bs[j];
-                    }
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            if (ok[it]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float z = v[it].get(j);
+                    if constexpr (HAS_PRO) z = act_t<ACT>(fmaf(z, sc[j], sh[j]), p.pro.act);
+                    o[j] = z;
                 }
-                o[j] = z;
+                if (has_bs) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] *= bs[j];
+                }
             }
             store8<float>(tile + pix * PS + cg * 8, o);
         }
     };
 
-    auto compute = [&](long t, const float* tile, float (&s1)[8], float (&s2)[8]) {
-        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
-        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
-        const int oy = ty * TH + row;
+    auto compute = [&](int b, int ty, int tx, const float* tile, float (&s1)[8], float (&s2)[8]) {
+        T* ybase = reinterpret_cast<T*>(p.y) + (((long)b * p.h + ty * TH) * p.w_ + tx * TW) * p.ldy;   // tile origin
+        const bool rowok = ty * TH + row < p.h && cok;
+        const int xlim = p.w_ - tx * TW;                          // x0 + o < xlim
         raw8<T> oc[4];
-        if (p.accumulate && oy < p.h && cok) {
+        if (p.accumulate && rowok) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const int ox = tx * TW + x0 + o;
-                if (ox < p.w_) oc[o].load(reinterpret_cast<const T*>(p.y) + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0);
-            }
+            for (int o = 0; o < 4; ++o)
+                if (x0 + o < xlim) oc[o].load(ybase + ooff + o * p.ldy);
         }
         float acc[4][8];
+        if (p.bias) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[o][j] = (p.bias && c0 + j < p.c) ? p.bias[c0 + j] : 0.f;
+                for (int j = 0; j < 8; ++j) acc[o][j] = (c0 + j < p.c) ? p.bias[c0 + j] : 0.f;
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+        }
 #pragma unroll 1
         for (int dy = 0; dy < 3; ++dy) {
             float wr[3][8], in[6][8];
@@ -226,13 +280,11 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 for (int k = 0; k < 3; ++k)
                     fma8(in[o + k], wr[k], acc[o]);
         }
-        if (oy < p.h && cok) {
-            T* yout = reinterpret_cast<T*>(p.y);
+        if (rowok) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                const int ox = tx * TW + x0 + o;
-                if (ox >= p.w_) continue;
-                T* dst = yout + (((long)b * p.h + oy) * p.w_ + ox) * p.ldy + c0;
+                if (x0 + o >= xlim) continue;
+                T* dst = ybase + ooff + o * p.ldy;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
                 if (p.accumulate) {
@@ -246,34 +298,33 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 
     __syncthreads();                                             // weights + zeroed `red` visible
     if (loader) {
-        const TileRange tr = tile_range(p.ntiles);
-        long t = tr.t0;
+        TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
         int buf = 0;
-        if (t < tr.end) stage(t, tile_base);
+        if (ti.valid()) stage(ti.b, ti.ty, ti.tx, tile_base);
         __syncthreads();
-        for (; t < tr.end; t += tr.step) {
-            const long tn = t + tr.step;
-            if (tn < tr.end) stage(tn, tile_base + (buf ^ 1) * HALO * PS);
+        while (ti.valid()) {
+            ti.next();                                           // the tile the compute waves will consume next
+            if (ti.valid()) stage(ti.b, ti.ty, ti.tx, tile_base + (buf ^ 1) * HALO * PS);
             __syncthreads();
             buf ^= 1;
         }
     } else {
         float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (DB) {
-            const TileRange tr = tile_range(p.ntiles);
-            long t = tr.t0;
+            TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
             int buf = 0;
             __syncthreads();
-            for (; t < tr.end; t += tr.step) {
-                compute(t, tile_base + buf * HALO * PS, s1, s2);
+            for (; ti.valid(); ti.next()) {
+                compute(ti.b, ti.ty, ti.tx, tile_base + buf * HALO * PS, s1, s2);
                 __syncthreads();
                 buf ^= 1;
             }
         } else {
-            for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-                stage(t, tile_base);
+            TileIter ti; ti.init(TileRange{(long)blockIdx.x, p.ntiles, (long)gridDim.x}, p.tiles_x, p.tiles_y);
+            for (; ti.valid(); ti.next()) {
+                stage(ti.b, ti.ty, ti.tx, tile_base);
                 __syncthreads();
-                compute(t, tile_base, s1, s2);
+                compute(ti.b, ti.ty, ti.tx, tile_base, s1, s2);
                 __syncthreads();
             }
         }
@@ -400,7 +451,7 @@ int launch_fwd2_inst(Dw2Params& p, dim3 grid, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISA_ELAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((dw2_fwd_kernel<T, HAS_PRO, ACT, DB>), grid, dim3(DB ? 512 : 256), lds, s, p);
+    hipLaunchKernelGGL((dw2_fwd_kernel<T, HAS_PRO, ACT, DB>), grid, dim3(DB ? 768 : 256), lds, s, p);
     return launch_status();
 }
 
@@ -523,26 +574,46 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     static_assert(NIT % NB == 0, "staging chunks");
     const bool want_xred = XMODE == 1 || (XMODE == 2 && p.xred != nullptr);
 
-    auto stage = [&](long t, float* xt, T* dt) {
-        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
-        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
+    // tile-invariant halo slot geometry (see dw2_fwd_kernel): per tile a scalar base per tensor and, on border tiles,
+    // four scalar bounds
+    int hrc[NIT], hog[NIT], hoy[NIT], hox[NIT];
+    bool hok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pix = (ltid + it * 256) >> 2;
+        const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
+        const int cc0 = cok ? c0 : c_base;
+        hrc[it] = (rr << 16) | cc;
+        hog[it] = (rr * p.w_ + cc) * p.ldg + cc0;
+        hoy[it] = (rr * p.w_ + cc) * p.ldy + cc0;
+        hox[it] = (rr * p.w_ + cc) * p.ldx + cc0;
+        hok[it] = pix < HALO && cok;
+    }
+    const int oox = (row * p.w_ + x0) * p.ldx + c0, oodx = (row * p.w_ + x0) * p.lddx + c0, ooa = (row * p.w_ + x0) * p.lda + c0;
+
+    auto stage = [&](int b, int ty, int tx, float* xt, T* dt) {
+        const long horg = ((long)b * p.h + ty * TH - 1) * p.w_ + tx * TW - 1;           // halo origin pixel (may lie outside)
+        const T* gb = gin + horg * p.ldg; const T* yb = yin + horg * p.ldy; const T* xb = xin + horg * p.ldx;
+        const int rlo = 1 - ty * TH, rhi = p.h + 1 - ty * TH, clo = 1 - tx * TW, chi = p.w_ + 1 - tx * TW;
+        const bool interior = rlo <= 0 && rhi >= TH + 2 && clo <= 0 && chi >= TW + 2;
+        bool okk[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = hrc[it] >> 16, cc = hrc[it] & 0xffff;
+            okk[it] = hok[it] && (interior || (rr >= rlo && rr < rhi && cc >= clo && cc < chi));
+        }
         {   // ---- dy = BN-backward(g, y) with halo
             float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
             ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
             ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
 #pragma unroll
             for (int it0 = 0; it0 < NIT; it0 += NB) {
-                raw8<T> gv[NB], yv[NB]; bool ok[NB];
+                raw8<T> gv[NB], yv[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int pix = (ltid + (it0 + u) * 256) >> 2;
-                    const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
-                    const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
-                    ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
-                    if (ok[u]) {
-                        const long po = ((long)b * p.h + gy) * p.w_ + gx;
-                        gv[u].load(gin + po * p.ldg + c0);
-                        yv[u].load(yin + po * p.ldy + c0);
+                    if (okk[it0 + u]) {
+                        gv[u].load(gb + hog[it0 + u]);
+                        yv[u].load(yb + hoy[it0 + u]);
                     }
                 }
 #pragma unroll
@@ -551,16 +622,16 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                     if (pix >= HALO) continue;
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float v = 0.f;
-                        if (ok[u]) {
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                    if (okk[it0 + u]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
                             const float yy = yv[u].get(j);
                             const float z = fmaf(yy, sc[j], sh[j]);
                             const float dz = gv[u].get(j) * act_grad_t<YACT>(z, p.yact);
                             const float yh = (yy - mu[j]) * is[j];
-                            v = sc[j] * (dz - k0[j] - yh * k1[j]);
+                            o[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
                         }
-                        o[j] = v;
                     }
                     store8<T>(dt + pix * PSD + cg * 8, o);
                 }
@@ -572,25 +643,21 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             ld8(cst + 6 * CB + cg * 8, sc); ld8(cst + 7 * CB + cg * 8, sh);
 #pragma unroll
             for (int it0 = 0; it0 < NIT; it0 += NB) {
-                raw8<T> xv[NB]; bool ok[NB];
+                raw8<T> xv[NB];
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int pix = (ltid + (it0 + u) * 256) >> 2;
-                    const int rr = pix / (TW + 2), cc = pix - rr * (TW + 2);
-                    const int gy = ty * TH + rr - 1, gx = tx * TW + cc - 1;
-                    ok[u] = pix < HALO && cok && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
-                    if (ok[u]) xv[u].load(xin + (((long)b * p.h + gy) * p.w_ + gx) * p.ldx + c0);
-                }
+                for (int u = 0; u < NB; ++u)
+                    if (okk[it0 + u]) xv[u].load(xb + hox[it0 + u]);
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int pix = (ltid + (it0 + u) * 256) >> 2;
                     if (pix >= HALO) continue;
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float v = 0.f;
-                        if (ok[u]) v = XMODE ? act_t<XACT>(fmaf(xv[u].get(j), sc[j], sh[j]), p.xact) : xv[u].get(j);
-                        o[j] = v;
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                    if (okk[it0 + u]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            o[j] = XMODE ? act_t<XACT>(fmaf(xv[u].get(j), sc[j], sh[j]), p.xact) : xv[u].get(j);
                     }
                     store8<float>(xt + pix * PS + cg * 8, o);
                 }
@@ -599,22 +666,22 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         }
     };
 
-    auto compute = [&](long t, const float* xt, const T* dt, float (&acc)[9][8], float (&s0)[8], float (&s1)[8]) {
-        const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
-        const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
-        const int oy = ty * TH + row;
+    auto compute = [&](int b, int ty, int tx, const float* xt, const T* dt, float (&acc)[9][8], float (&s0)[8], float (&s1)[8]) {
+        const long torg = ((long)b * p.h + ty * TH) * p.w_ + tx * TW;                      // tile origin pixel
+        const T* xo = xin + torg * p.ldx + oox; T* dxb = dxo + torg * p.lddx + oodx;
+        const T* adb = reinterpret_cast<const T*>(p.addend) + torg * p.lda + ooa;
+        const bool rowok = ty * TH + row < p.h && cok;
+        const int xlim = p.w_ - tx * TW;                                                   // x0 + o < xlim
         // operands of the epilogue (old dx for accumulate, raw x for the BN(x) sums) are requested before the
         // stencil so their latency hides behind it: a compute wave has no sibling wave to switch to
         raw8<T> xc[4], oc[4], ad[4];
-        if (oy < p.h && cok) {
+        if (rowok) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                const int ox = tx * TW + x0 + o;
-                if (ox >= p.w_) continue;
-                const long po = ((long)b * p.h + oy) * p.w_ + ox;
-                if (want_xred) xc[o].load(xin + po * p.ldx + c0);
-                if (p.accumulate) oc[o].load(dxo + po * p.lddx + c0);
-                if constexpr (XMODE == 0) { if (p.addend) ad[o].load(reinterpret_cast<const T*>(p.addend) + po * p.lda + c0); }
+                if (x0 + o >= xlim) continue;
+                if (want_xred) xc[o].load(xo + o * p.ldx);
+                if (p.accumulate) oc[o].load(dxb + o * p.lddx);
+                if constexpr (XMODE == 0) { if (p.addend) ad[o].load(adb + o * p.lda); }
             }
         }
         {   // ---- data gradient: dx tile = flipped taps over dy (halo), then BN(x)-backward sums
@@ -636,7 +703,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                     for (int k = 0; k < 3; ++k)
                         fma8(in[o + k], wr[k], a[o]);
             }
-            if (oy < p.h && cok) {
+            if (rowok) {
                 float xs[8], xh[8], xm[8], xi[8];
                 if (want_xred) {
                     ld8(cst + 6 * CB + cg * 8, xs); ld8(cst + 7 * CB + cg * 8, xh);
@@ -644,10 +711,8 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 }
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    const int ox = tx * TW + x0 + o;
-                    if (ox >= p.w_) continue;
-                    const long po = ((long)b * p.h + oy) * p.w_ + ox;
-                    T* dst = dxo + po * p.lddx + c0;
+                    if (x0 + o >= xlim) continue;
+                    T* dst = dxb + o * p.lddx;
                     if (p.accumulate) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) a[o][j] += oc[o].get(j);
@@ -699,14 +764,13 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // max(loader set, compute set) instead of their sum.  Both sides execute the same number of barriers.
     __syncthreads();                                             // constants + zeroed `red` visible
     if (loader) {
-        const TileRange tr = tile_range(p.ntiles);
-        long t = tr.t0;
+        TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
         int buf = 0;
-        if (t < tr.end) stage(t, xt_base, dt_base);
+        if (ti.valid()) stage(ti.b, ti.ty, ti.tx, xt_base, dt_base);
         __syncthreads();                                         // first tile staged
-        for (; t < tr.end; t += tr.step) {
-            const long tn = t + tr.step;
-            if (tn < tr.end) stage(tn, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
+        while (ti.valid()) {
+            ti.next();                                           // the tile the compute waves consume next
+            if (ti.valid()) stage(ti.b, ti.ty, ti.tx, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
             __syncthreads();
             buf ^= 1;
         }
@@ -719,20 +783,20 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
         if constexpr (DB) {
-            const TileRange tr = tile_range(p.ntiles);
-            long t = tr.t0;
+            TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
             int buf = 0;
             __syncthreads();                                     // first tile staged
-            for (; t < tr.end; t += tr.step) {
-                compute(t, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
+            for (; ti.valid(); ti.next()) {
+                compute(ti.b, ti.ty, ti.tx, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
                 __syncthreads();
                 buf ^= 1;
             }
         } else {
-            for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-                stage(t, xt_base, dt_base);
+            TileIter ti; ti.init(TileRange{(long)blockIdx.x, p.ntiles, (long)gridDim.x}, p.tiles_x, p.tiles_y);
+            for (; ti.valid(); ti.next()) {
+                stage(ti.b, ti.ty, ti.tx, xt_base, dt_base);
                 __syncthreads();
-                compute(t, xt_base, dt_base, acc, s0, s1);
+                compute(ti.b, ti.ty, ti.tx, xt_base, dt_base, acc, s0, s1);
                 __syncthreads();                                 // tile fully consumed before it is restaged
             }
         }

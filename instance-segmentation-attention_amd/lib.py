@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libisa_kernels.so")
+# ISA_KERNELS_LIB: another build of the same library (A/B kernel timings inside one GPU session; scripts/kbench.py)
+LIB_PATH = os.environ.get("ISA_KERNELS_LIB") or os.path.join(_HERE, "libisa_kernels.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3, 4
