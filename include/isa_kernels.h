@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-enum { ISA_F32 = 0, ISA_BF16 = 1 };
+enum { ISA_F32 = 0, ISA_BF16 = 1,
+       ISA_F16 = 2 };  /* fp16 storage: accepted by the attention operators (isa_sdp_attention, isa_sdp_scores) only */
 enum { ISA_ACT_NONE = 0, ISA_ACT_RELU = 1, ISA_ACT_RELU6 = 2, ISA_ACT_LEAKY = 3, ISA_ACT_TANH = 4 };
 enum { ISA_STAT_REPLICAS = 8 };   /* layout of every per-channel statistics buffer: [8][2*C] */
 enum { ISA_OK = 0, ISA_EINVAL = -1, ISA_EALIGN = -2, ISA_EDTYPE = -3, ISA_ELAUNCH = -4, ISA_ENOMEM = -5 };
@@ -311,12 +312,33 @@ int isa_adadelta(float* p, const float* g, float* sq, float* acc, int64_t n, flo
                  const float* sqnorm, float max_norm, float gscale, const float* lr_dev, void* stream);
 
 /* ---- the reference's named attention operators (modules/utils.py; dead at HEAD) --
- * a19 ScaledDotProductAttention.forward (utils.py:316-327): out[bh,lq,dv] = softmax(mask(q k^T / T)) v,
- *     attn[bh,lq,L] optional.  q[bh,lq,dk] k[bh,L,dk] v[bh,L,dv] contiguous, dtype ISA_F32|ISA_BF16;
- *     mask[bh,lq,L] bytes, non-zero = masked.  K/V are streamed once (online softmax, LDS-staged tiles). */
+ * a19 ScaledDotProductAttention.forward (utils.py:316-327) as MultiHeadAttention calls it (utils.py:167-225):
+ *     out = softmax(mask(q k^T / T)) v, attn[(head*b), lq, L] optional (fp32).  Few queries against L = H*W keys.
+ *     Operands: k, v [bh, L, heads*d], q [bh, lq, heads*d], out [bh, lq, heads*d] with `heads` heads interleaved in a
+ *     row - the layout the Linear projections produce, so the reference's head-major permute (utils.py:200-202) is
+ *     never materialised; heads = 1 means plain contiguous [bh, L, d] operands (then bh = batch*heads).
+ *     dtype ISA_F32 | ISA_BF16 | ISA_F16.  mask: bytes, non-zero = masked, [bh, lq, L] or, with mask_per_head,
+ *     [heads*bh, lq, L] (the reference repeats the mask per head).  attn rows are ordered head-major ((h*bh + b)*lq + q)
+ *     like the reference's (n*b) batch.
+ *     d_k = d_v = 12 (config.py:22-25): split-L streaming kernel - K/V read once in 16-byte coalesced loads, LDS-staged
+ *     tiles of `tile_keys` keys (0 = 512; 256/512/1024), lane = key, online softmax, shuffle merges, one partial per
+ *     workgroup in `ws` and a flash-decoding merge.  Other head dims <= 32: a one-workgroup-per-query fallback
+ *     (heads = 1, f32/bf16).  ws: fp32 scratch, bh*heads*lq*(nsplit*(2+d)+2) floats (64 K floats always suffice). */
 int isa_sdp_attention(const void* q, const void* k, const void* v, const uint8_t* mask, void* out,
                       float* attn, int32_t bh, int32_t lq, int64_t L, int32_t dk, int32_t dv,
-                      float temperature, int32_t dtype, void* stream);
+                      float temperature, int32_t dtype, int32_t heads, int32_t mask_per_head,
+                      float* ws, int64_t ws_floats, int32_t tile_keys, void* stream);
+/* The `last=True` branch (utils.py:203-209, 310-313): out[(h*b), lq, L] = q k^T (ScaledDotProductAttention) or
+ * sigmoid(q k^T) (MultiHeadAttention: sigmoid != 0), no temperature, no softmax; same operand layout. */
+int isa_sdp_scores(const void* q, const void* k, float* out, int32_t b, int32_t heads, int32_t lq, int64_t L,
+                   int32_t d, int32_t dtype, int32_t sigmoid, void* stream);
+/* y[r,:] = LayerNorm(W x[r,:] + bias + residual[r,:]): the small dense layers around the attention core (w_qs on the few
+ * query rows, fc + layer_norm on the attended rows, utils.py:189-201).  fp32, n <= 64; gamma == NULL: no LayerNorm. */
+int isa_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* gamma,
+                  const float* beta, float eps, int32_t rows, int32_t k, int32_t n, float* y, void* stream);
+/* out = InstanceNorm2d(x + res) (utils.py:301-302: affine=False, biased variance); sums: zeroed float[n][2c]. */
+int isa_instance_norm_res(const isa_tensor* x, const isa_tensor* res, const isa_tensor* out, float eps, float* sums,
+                          void* stream);
 /* a20 _ScalePDAttention core (utils.py:276-299): per-pixel softmax over the 3x3 neighbourhood at `dilation` */
 int isa_local_attention(const isa_tensor* q, const isa_tensor* k, const isa_tensor* v, const float* nomask,
                         const isa_tensor* out, int32_t dilation, void* stream);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ISA_KERNELS_LIB: another build of the same library (A/B kernel timings inside one GPU session; scripts/kbench.py)
 LIB_PATH = os.environ.get("ISA_KERNELS_LIB") or os.path.join(_HERE, "libisa_kernels.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3, 4
 IN_1X1, IN_3X3, IN_GATHER2 = 0, 1, 2
 OUT_PLAIN, OUT_SHUFFLE2 = 0, 1
@@ -107,7 +107,10 @@ SIGNATURES = {
     "isa_scale_bc": [P_T, VP, P_T, I32, VP],
     "isa_sqnorm": [VP, I64, F, VP, VP],
     "isa_adadelta": [VP, VP, VP, VP, I64, F, F, F, F, VP, F, F, VP, VP],
-    "isa_sdp_attention": [VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, VP],
+    "isa_sdp_attention": [VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, I32, I32, VP, I64, I32, VP],
+    "isa_sdp_scores": [VP, VP, VP, I32, I32, I32, I64, I32, I32, I32, VP],
+    "isa_linear_ln": [VP, VP, VP, VP, VP, VP, F, I32, I32, I32, VP, VP],
+    "isa_instance_norm_res": [P_T, P_T, P_T, F, VP, VP],
     "isa_local_attention": [P_T, P_T, P_T, VP, P_T, I32, VP],
     "isa_point_query": [VP, P_T, VP, VP],
     "isa_image_ex": [VP, P_T, VP],
@@ -154,6 +157,8 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16            # attention operators only
     raise IsaError("unsupported activation dtype %s" % dt)
 
 

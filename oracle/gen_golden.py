@@ -204,6 +204,27 @@ def byname_cases(store):
     with torch.no_grad():
         o = dec(qq, enc, None)
     store["pq/q"], store["pq/enc"], store["pq/out"] = qq.numpy(), enc.numpy(), o.numpy()
+    # a19 whole operator: MultiHeadAttention (utils.py:167-225) as configured (config.py:22-25), eval mode, both branches
+    mha = U.MultiHeadAttention(2, 24, 12, 12).eval()
+    for k_, v_ in mha.state_dict().items():
+        store["mha/sd/" + k_] = v_.numpy()
+    b, L = 2, 2048
+    mq = torch.from_numpy(rs.standard_normal((b, 1, 24)).astype(np.float32))
+    mk = torch.from_numpy(rs.standard_normal((b, L, 24)).astype(np.float32))
+    mv = torch.from_numpy(rs.standard_normal((b, L, 24)).astype(np.float32))
+    mmask = torch.from_numpy(rs.rand(b, 1, L) < 0.25)
+    with torch.no_grad():
+        o1, a1 = mha(mq, mk, mv, mask=mmask)
+        o2, _ = mha(mq, mk, mv, mask=mmask, last=True)
+    for nm, t in (("q", mq), ("k", mk), ("v", mv), ("out", o1), ("attn", a1), ("last", o2)):
+        store["mha/" + nm] = t.numpy()
+    store["mha/mask"] = mmask.numpy()
+    # a20 whole operator: _ScalePDAttention.forward incl. projections, fc and InstanceNorm (utils.py:248-303)
+    for k_, v_ in mod.state_dict().items():
+        store["local/sd/" + k_] = v_.numpy()
+    with torch.no_grad():
+        full = mod(qk, vv, nomask)
+    store["local/qk_in"], store["local/v_in"], store["local/out"] = qk.numpy(), vv.numpy(), full.numpy()
 
 
 def main():

@@ -25,7 +25,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
 def test_scaled_dot_product_attention(dtype, tol):
     A = ops()
     z = np.load(os.path.join(ROOT, "tests", "golden", "byname_ops.npz"))
@@ -60,3 +60,56 @@ def test_local_dilated_attention_and_point_query():
     assert rel(att, t("local/att")) < 1e-5
     pq = A.point_query_mask(t("pq/q"), t("pq/enc"))
     assert rel(pq, t("pq/out")) < 1e-5
+
+
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_sdp_tile_sizes_and_ragged_lengths(tile):
+    """Every LDS tile size of the sweep, lengths that are not multiples of the tile or of the split, several queries,
+    fully masked rows (NaN like the reference's softmax of all -inf) - against torch on the same operands."""
+    A = ops()
+    g = torch.Generator().manual_seed(tile)
+    for (bh, lq, L) in ((3, 1, 1), (2, 3, 1000), (5, 1, 4097), (1, 6, 70001)):
+        q, k, v = torch.randn(bh, lq, 12, generator=g), torch.randn(bh, L, 12, generator=g), torch.randn(bh, L, 12, generator=g)
+        mask = torch.rand(bh, lq, L, generator=g) < 0.3
+        if L > 1:
+            mask[0, 0] = True                                    # one fully masked row
+        out, attn = A.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), 12 ** 0.5, mask.cuda(), tile_keys=tile)
+        ref_a = torch.softmax((q @ k.transpose(1, 2) / 12 ** 0.5).masked_fill(mask, float("-inf")), 2)
+        ref_o = ref_a @ v
+        ok = ~torch.isnan(ref_o)
+        assert torch.equal(torch.isnan(out.cpu()), torch.isnan(ref_o)), (bh, lq, L)
+        assert float((out.cpu()[ok] - ref_o[ok]).abs().max()) < 1e-5 * max(1.0, float(ref_o[ok].abs().max()))
+        oka = ~torch.isnan(ref_a)
+        assert float((attn.cpu()[oka] - ref_a[oka]).abs().max()) < 1e-6 + 1e-5 * float(ref_a[oka].max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
+def test_multi_head_attention_whole_operator(dtype, tol):
+    """MultiHeadAttention (utils.py:167-225) with the reference's own parameters and vectors: projections, the
+    streaming attention over the interleaved heads, fc + LayerNorm, and the last=True sigmoid branch."""
+    A = ops()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "byname_ops.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    m = A.MultiHeadAttention(2, 24, 12, 12, dtype=dtype).cuda().eval()
+    m.load_state_dict({k[len("mha/sd/"):]: t(k) for k in z.files if k.startswith("mha/sd/")})
+    q, k, v, mask = t("mha/q").cuda(), t("mha/k").cuda(), t("mha/v").cuda(), t("mha/mask").cuda()
+    out, attn = m(q, k, v, mask=mask)
+    last, none = m(q, k, v, mask=mask, last=True)
+    torch.cuda.synchronize()
+    assert none is None and tuple(attn.shape) == tuple(z["mha/attn"].shape) and tuple(last.shape) == tuple(z["mha/last"].shape)
+    assert rel(out, t("mha/out")) < tol
+    assert rel(attn, t("mha/attn")) < tol
+    assert rel(last, t("mha/last")) < tol
+
+
+def test_scale_pd_attention_whole_operator():
+    """_ScalePDAttention (utils.py:248-303) with the reference's parameters: block-diagonal projections, the local
+    3x3-dilated softmax per head (incl. the reference's nomask.repeat indexing), fc and InstanceNorm2d(out + qk)."""
+    A = ops()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "byname_ops.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    m = A.ScalePDAttention(12, 12, 24, int(z["local/dilation"][0]), n_head=2).cuda().eval()
+    m.load_state_dict({k[len("local/sd/"):]: t(k) for k in z.files if k.startswith("local/sd/")})
+    out = m(t("local/qk_in").cuda(), t("local/v_in").cuda(), t("local/nomask").cuda())
+    torch.cuda.synchronize()
+    assert rel(out, t("local/out")) < 1e-4
