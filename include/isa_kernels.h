@@ -259,8 +259,16 @@ int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, const float* me
  * gather of attenet2.py:342-343): alpha[b,:] = softmax over pixels of ins[b, idx[b]] */
 int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
                     int64_t L, float* alpha, float* rowstat /*[n,2]*/, void* stream);
-/* DecoderLayer.sample eval branch (attenet2.py:324): first argmax per row, on device */
-int isa_row_argmax(const float* a, int32_t n, int64_t L, int32_t* out, void* stream);
+/* DecoderLayer.sample (attenet2.py:304-324): first argmax per row, on device.  race == NULL: the eval branch
+ * (argmax of alpha).  race != NULL ([n, L] draws from Exp(1)): argmax of alpha / race = one draw from
+ * Multinomial(alpha), the training branch (torch.multinomial's own single-sample form). */
+int isa_row_argmax(const float* a, const float* race, int32_t n, int64_t L, int32_t* out, void* stream);
+/* sem_seg_argmax = GT.argmax(1) (reseg.py:118) of the int64 one-hot target [n,2,h,w] as an fp32 {0,1} map [n, h*w] */
+int isa_onehot_map(const int64_t* onehot, int32_t n, int64_t hw, float* out, void* stream);
+/* F.dropout2d masks (utils.py:984,1104-1110) from uniform draws: out = (u < keep) / keep */
+int isa_dropout_mask(const float* u, int64_t n, float keep, float* out, void* stream);
+/* softmax over the channels of an NHWC logit map, written NCHW fp32 (Model.predict, model.py:486) */
+int isa_softmax_nchw(const isa_tensor* x, float* out, void* stream);
 /* UpDecoderLayer.resize (utils.py:841-846): f x f max-pool of the instance plane / of an fp32 map */
 int isa_pool_target(const int64_t* ins, const int32_t* idx, const float* src, int32_t nobj, int32_t n,
                     int32_t H, int32_t W, int32_t f, float* out, void* stream);

@@ -284,13 +284,16 @@ __global__ __launch_bounds__(1024) void ins_softmax_kernel(const float* merge, c
 }
 
 // ---- a11: s_t[b] = argmax_p alpha[b,p], first maximum wins (torch.argmax) -------------------------
-__global__ __launch_bounds__(1024) void row_argmax_kernel(const float* a, long L, int32_t* out) {
+// `race` (optional): the exponential race of DecoderLayer.sample's training branch - argmax_p alpha[p] / race[p] with
+// race ~ Exp(1) draws one index from Multinomial(alpha) (torch.multinomial's own single-sample form, attenet2.py:321)
+__global__ __launch_bounds__(1024) void row_argmax_kernel(const float* a, const float* race, long L, int32_t* out) {
     __shared__ float shv[16];
     __shared__ int shi[16];
     const int b = blockIdx.x;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (long p = threadIdx.x; p < L; p += 1024) {
-        const float v = a[(long)b * L + p];
+        float v = a[(long)b * L + p];
+        if (race) v = v / race[(long)b * L + p];
         if (v > best) { best = v; bi = (int)p; }
     }
 #pragma unroll
@@ -503,9 +506,58 @@ extern "C" int isa_ins_softmax(const float* merge, const int64_t* ins, const int
     return launch_status();
 }
 
-extern "C" int isa_row_argmax(const float* a, int32_t n, int64_t L, int32_t* out, void* stream) {
+extern "C" int isa_row_argmax(const float* a, const float* race, int32_t n, int64_t L, int32_t* out, void* stream) {
     if (!a || !out || n <= 0) return ISA_EINVAL;
-    hipLaunchKernelGGL(row_argmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), a, (long)L, out);
+    hipLaunchKernelGGL(row_argmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), a, race, (long)L, out);
+    return launch_status();
+}
+
+namespace {
+// sem_seg_argmax = GT.argmax(1) of the int64 one-hot target (reseg.py:118), as the fp32 {0,1} map the head consumes
+__global__ __launch_bounds__(256) void onehot_map_kernel(const int64_t* oh, long hw, long total, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / hw, p = i - b * hw;
+        out[i] = oh[(b * 2 + 1) * hw + p] > oh[(b * 2) * hw + p] ? 1.f : 0.f;     // first maximum wins (torch.argmax)
+    }
+}
+// F.dropout2d masks from uniform draws: mask = (u < keep) / keep
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const float* u, long n, float keep, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = u[i] < keep ? 1.f / keep : 0.f;
+}
+// softmax over the channels of an NHWC logit map, written as NCHW fp32 (Model.predict, model.py:486)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_nchw_kernel(View x, float* out) {
+    const long hw = (long)x.h * x.w, pixels = hw * x.n;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < pixels; pix += (long)gridDim.x * 256) {
+        const T* p = reinterpret_cast<const T*>(x.data) + pix * x.ld;
+        float m = -INFINITY;
+        for (int c = 0; c < x.c; ++c) m = fmaxf(m, st<T>::ld(p + c));
+        float s = 0.f;
+        for (int c = 0; c < x.c; ++c) s += expf(st<T>::ld(p + c) - m);
+        const long b = pix / hw, q = pix - b * hw;
+        for (int c = 0; c < x.c; ++c) out[(b * x.c + c) * hw + q] = expf(st<T>::ld(p + c) - m) / s;
+    }
+}
+}  // namespace
+
+extern "C" int isa_onehot_map(const int64_t* onehot, int32_t n, int64_t hw, float* out, void* stream) {
+    if (!onehot || !out || n <= 0 || hw <= 0) return ISA_EINVAL;
+    hipLaunchKernelGGL(onehot_map_kernel, dim3(grid_cap(cdiv(n * hw, 256))), dim3(256), 0, as_stream(stream), onehot, (long)hw, (long)n * hw, out);
+    return launch_status();
+}
+
+extern "C" int isa_dropout_mask(const float* u, int64_t n, float keep, float* out, void* stream) {
+    if (!u || !out || n <= 0 || !(keep > 0.f)) return ISA_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_cap(cdiv(n, 256), 256)), dim3(256), 0, as_stream(stream), u, (long)n, keep, out);
+    return launch_status();
+}
+
+extern "C" int isa_softmax_nchw(const isa_tensor* x, float* out, void* stream) {
+    if (!tensor_ok(x, 1) || !out) return ISA_EINVAL;
+    const int grid = grid_cap(cdiv((long)x->n * x->h * x->w, 256));
+    DISPATCH_T(x->dtype,
+        hipLaunchKernelGGL(softmax_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(x), out),
+        hipLaunchKernelGGL(softmax_nchw_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(x), out));
     return launch_status();
 }
 

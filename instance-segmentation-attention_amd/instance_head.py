@@ -167,7 +167,9 @@ class InstanceHead:
             return
         total = max_iter * sum(3 * n * oc for oc in OUT_CH)
         keep = 1.0 - self.drop_rate
-        self._mask_pool = (torch.rand(total, device=self.E.device) < keep).float() / keep   # host-side RNG plumbing
+        u = torch.rand(total, device=self.E.device)          # torch supplies the random numbers (graph-safe generator)
+        self._mask_pool = torch.empty_like(u)
+        L.check(self.E.lib.isa_dropout_mask(L.ptr(u), total, keep, L.ptr(self._mask_pool), self.E.st()), "isa_dropout_mask")
 
     def _drop_mask(self, n, c, active):
         if not active or self.drop_rate <= 0:
@@ -313,11 +315,11 @@ class InstanceHead:
                 # attenet2.py:304-321 `sample`: training draws s_t ~ Multinomial(alpha), eval takes the argmax.
                 # The draw is argmax(alpha / Exp(1)) (the exponential-race form torch.multinomial itself uses
                 # for one sample); torch supplies the random numbers (graph-safe generator), the row argmax is ours.
-                src = alpha
+                race = None
                 if training and self.sample_in_training:
-                    src = alpha.view(n, Lp) / torch.empty(n, Lp, dtype=torch.float32, device=alpha.device).exponential_(1.0)
+                    race = torch.empty(n, Lp, dtype=torch.float32, device=alpha.device).exponential_(1.0)
                 s_t = E.arena.alloc((n,), torch.int32)
-                L.check(E.lib.isa_row_argmax(L.ptr(src), n, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
+                L.check(E.lib.isa_row_argmax(L.ptr(alpha), L.ptr(race), n, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
             targets = []
             for f in FACTORS:
                 t = E.f32(n * (H // f) * (W // f))

@@ -90,7 +90,10 @@ SIGNATURES = {
     "isa_maskbn_finalize": [VP, VP, I32, I32, VP, VP, VP, F, I32, VP],
     "isa_maskbn_apply_pool": [P_T, VP, VP, VP, VP, F, VP, VP],
     "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, VP],
-    "isa_row_argmax": [VP, I32, I64, VP, VP],
+    "isa_row_argmax": [VP, VP, I32, I64, VP, VP],
+    "isa_onehot_map": [VP, I32, I64, VP, VP],
+    "isa_dropout_mask": [VP, I64, F, VP, VP],
+    "isa_softmax_nchw": [P_T, VP, VP],
     "isa_pool_target": [VP, VP, VP, I32, I32, I32, I32, I32, VP, VP],
     "isa_concat_aux": [P_T, VP, VP, I32, I32, I32, VP],
     "isa_gate": [P_T, P_T, P_T, VP, VP],

@@ -144,5 +144,5 @@ class Model(object):
             # the shipped ModelSettings hit an UnboundLocalError here (reseg.py:126); the only working
             # inference mode is the semantic one — same contract, clearer message
             raise RuntimeError("predict() needs a model built with use_instance_segmentation=False")
-        sem_out, _ = m(False, images.contiguous())
-        return torch.nn.functional.softmax(sem_out, dim=1).cpu()             # boundary glue on the output
+        m(False, images.contiguous())
+        return m.net.softmax_nchw(m._last_sem).cpu()                          # softmax over classes (model.py:486)

@@ -145,6 +145,20 @@ class Network:
             E.tape.append(bwd)
         return scal
 
+    def onehot_map(self, sem_onehot: torch.Tensor) -> torch.Tensor:
+        """int64 one-hot [n,2,h,w] -> fp32 {0,1} map [n, h*w] (sem_seg_argmax of reseg.py:118, on the device)."""
+        E = self.E
+        n, c, h, w = sem_onehot.shape
+        assert c == 2 and sem_onehot.dtype == torch.int64
+        out = E.f32(n, h * w)
+        L.check(E.lib.isa_onehot_map(L.ptr(sem_onehot), n, h * w, L.ptr(out), E.st()), "isa_onehot_map")
+        return out
+
+    def softmax_nchw(self, logits: Act) -> torch.Tensor:
+        out = torch.empty((logits.n, logits.c, logits.h, logits.w), dtype=torch.float32, device=logits.buf.device)
+        L.check(self.E.lib.isa_softmax_nchw(logits.d(), L.ptr(out), self.E.st()), "isa_softmax_nchw")
+        return out
+
     def argmax_map(self, logits: Act):
         E = self.E
         out = E.new_act(logits.n, logits.h, logits.w, 1)

@@ -234,7 +234,8 @@ class ReSeg(nn.Module):
         self._last_sem = sem                       # logits view in the step's arena (sem_costs)
         sem_out = net.to_nchw(sem)
         if has_gt:
-            sem_argmax = sem_seg_target.to(dev).argmax(1).unsqueeze(1).float()
+            # (the map lives in the step's arena: the caller gets a copy)
+            sem_argmax = net.onehot_map(sem_seg_target.to(dev).contiguous()).view(x.shape[0], 1, sem.h, sem.w).clone()
         else:
             sem_argmax = net.to_nchw(net.argmax_map(sem))
         if not self.use_instance_seg:

@@ -66,7 +66,7 @@ class Trainer:
                     order = list(range(k))
                     random.shuffle(order)
                     selected_idx.append(order)
-            sem_map = sem.argmax(1).reshape(x.shape[0], -1).float().contiguous()
+            sem_map = net.onehot_map(sem)                    # GT.argmax(1) (reseg.py:118) as the fp32 map the head reads
             rec = m.head.forward(x_dec, feats, sem_map, ins, n_ins, True, selected_idx, injected_s_t, capture,
                                  idx_dev=idx_dev)
             m.last_record = rec

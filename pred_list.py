@@ -4,7 +4,7 @@ code/pred_list.py:16-99 (flags --lst/--model/--usegpu/--dataset; outputs <name>.
 outputs/<dataset>/<model dir>-<model name>/<subset>/).
 
 Per image (lib/prediction.py:33-50,116-124): read RGB, resize to 256x256 (bilinear, `image_resizer`), ImageEx +
-standardization (on the device here: isa_image_ex), network forward, softmax > 0.5, nearest-neighbour up-sampling
+standardization (on the device here: isa_image_ex), network forward, softmax > 0.5 (= the arg-max map), nearest-neighbour up-sampling
 to the original size (cv2.INTER_NEAREST index rule), x255, PNG.  The instance outputs of the reference
 (-ins_mask*.png, -n_objects.npy) come from `Prediction.cluster`, which is dead at HEAD (the
 GT-free instance path raises UnboundLocalError, reseg.py:126) and are not produced.
@@ -70,9 +70,9 @@ def main():
         imgs = [ld() for ld in loaders[s:s + opt.batch]]
         small = np.stack([np.asarray(Image.fromarray(im).resize((W, H), Image.BILINEAR)) for im in imgs])
         x = torch.from_numpy(small).cuda()               # uint8 [B,H,W,3]: ImageEx runs on the device
-        sem_out, _ = net.infer_graphed(x) if len(imgs) == opt.batch else net(False, x)
-        prob = torch.softmax(sem_out, dim=1)[:, 1]
-        fg = (prob > 0.5).to(torch.uint8).cpu().numpy()  # pred.py:117-121
+        _, sem_arg = net.infer_graphed(x) if len(imgs) == opt.batch else net(False, x)
+        # softmax(l)[1] > 0.5 (pred.py:117-121) is l1 > l0: the arg-max map the library already returns
+        fg = (sem_arg[:, 0] > 0.5).to(torch.uint8).cpu().numpy()
         for im, name, m in zip(imgs, names[s:s + opt.batch], fg):
             d = os.path.join(out_dir, name)
             os.makedirs(d, exist_ok=True)

@@ -97,7 +97,11 @@ def _check_gradients(m, z64, z32, label, rerun=None):
           "%.2e), p90 %.2e (%.2e)" % (label, len(rows), rows[0][0], rows[0][1], rows[0][2], rows[0][3], np.median(errs),
                                       np.median(floors), np.percentile(errs, 90), np.percentile(floors, 90)))
     assert not bad, bad[:5]
-    assert np.median(errs) <= 3.0 * np.median(floors) + 1e-4 and np.percentile(errs, 90) <= 3.0 * np.percentile(floors, 90) + 1e-4
+    # distribution: one flip in the last decoder level moves EVERY upstream tensor, so the median of a run swings between
+    # 1e-3 and 3e-3 here; the run-to-run jitter of the HIP path itself (same metric) is part of the allowance
+    jit = np.array([jitter[r[1]] for r in rows])
+    assert np.median(errs) <= 3.0 * (np.median(floors) + np.median(jit)) + 1e-4, (np.median(errs), np.median(floors), np.median(jit))
+    assert np.percentile(errs, 90) <= 3.0 * (np.percentile(floors, 90) + np.percentile(jit, 90)) + 1e-4
     # the 9 tensors that never receive a gradient stay exactly zero and are outside the trained slice
     for k in z64.files:
         if k.startswith("grad_none/"):

@@ -39,3 +39,34 @@ def test_pred_list_synthetic_run(tmp_path):
         mask = np.asarray(Image.open(os.path.join(out, n, n + "-fg_mask.png")))
         assert mask.shape == img.shape[:2]                      # up-sampled back to the original size
         assert set(np.unique(mask)) <= {0, 255}
+
+
+@pytest.mark.gpu
+def test_pred_image_in_palette_png_out(tmp_path):
+    """pred.py contract (code/pred.py:114-123): an image file in, <name>-fg_mask.png out - a palette ('P') PNG at the
+    ORIGINAL size holding {0, 255}; and the same mask pred_list.py writes for that image."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (301, 417, 3), dtype=np.uint8)
+    src = str(tmp_path / "leaf_007.png")
+    Image.fromarray(img).save(src)
+    out = str(tmp_path / "single")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "pred.py"), "--image", src, "--output", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = Image.open(os.path.join(out, "leaf_007-fg_mask.png"))
+    assert m.mode == "P" and m.size == (417, 301)
+    # what the reference's own conversion chain yields for a {0, 255} float image
+    want_values = set(np.unique(np.asarray(Image.fromarray(np.array([[0.0, 255.0]], dtype=np.float32)).convert("P"))))
+    assert set(np.unique(np.asarray(m))) <= want_values
+    lst = str(tmp_path / "val_list.txt")
+    open(lst, "w").write(src + "\n")
+    out2 = str(tmp_path / "listed")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "pred_list.py"), "--lst", lst, "--output", out2],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m2 = np.asarray(Image.open(os.path.join(out2, "leaf_007", "leaf_007-fg_mask.png")))
+    assert np.array_equal(np.asarray(m.convert("L")) > 127, m2 > 127)
