@@ -181,15 +181,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                 }
                 if constexpr (HAS_PRO) {
                     if (vcur) {
+                        // scale / shift of the fragment's 16 channels as eight ds_read_b128.  Channels >= cin arrive as 0
+                        // from frag_load and are multiplied by zero weight columns, so only finiteness matters there and
+                        // there is no per-element bounds test; the per-image multiplier is a wave-uniform branch around
+                        // its own loop.  The element-wise form compiled to 32 ds_read_b32, 16 waits and 16 branches per
+                        // fragment.
+                        float sc[16], sh[16];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const int k = kcur + j;
-                            float v = frag_get<T>(cur, j);
-                            v = act_t<ACT>(fmaf(v, pro_tab[k], pro_tab[p.kp + k]), p.pro.act);
-                            if (p.pro.bscale) v *= (k < p.cin) ? p.pro.bscale[(long)pb * p.cin + k] : 0.f;
-                            if (k >= p.cin) v = 0.f;
-                            frag_set<T>(cur, j, v);
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(pro_tab + kcur + 4 * q);
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(pro_tab + p.kp + kcur + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; }
                         }
+                        float v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) v[j] = act_t<ACT>(fmaf(frag_get<T>(cur, j), sc[j], sh[j]), p.pro.act);
+                        if (p.pro.bscale) {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) v[j] *= (kcur + j < p.cin) ? p.pro.bscale[(long)pb * p.cin + kcur + j] : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) frag_set<T>(cur, j, v[j]);
                     }
                 }
                 const int gl = g - g_begin;

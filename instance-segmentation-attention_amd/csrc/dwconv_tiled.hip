@@ -96,11 +96,16 @@ __device__ __forceinline__ void stage_tile(const Dw2Params& p, const ProRegs& r,
 // acc[j] += x[j] * w[j] for 8 channels as four v_pk_fma_f32 (packed fp32: two FMAs per lane per issue)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fma8(const float (&x)[8], const float (&w)[8], float (&acc)[8]) {
+#ifdef ISA_DW_SCALAR_FMA
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(x[j], w[j], acc[j]);
+#else
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const f32x2 r = __builtin_elementwise_fma(f32x2{x[j], x[j + 1]}, f32x2{w[j], w[j + 1]}, f32x2{acc[j], acc[j + 1]});
         acc[j] = r[0]; acc[j + 1] = r[1];
     }
+#endif
 }
 
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
