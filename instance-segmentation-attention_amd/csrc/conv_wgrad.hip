@@ -430,12 +430,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgParams p) {
                         for (int j = 0; j < 8; ++j) raw[j] = (ck0 + j < p.cin) ? src[j] : (bf16_t)0.f;
                     }
                     if (has_pro) {
+                        // wave-uniform tests hoisted out of the element loop (the per-image multiplier and the channel
+                        // tail were a branch and a select per element)
+                        float z[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float z = act_t<ACT>(fmaf((float)raw[j], psc[j], psh[j]), p.pro.act);
-                            if (p.pro.bscale) z *= p.pro.bscale[pb * p.cin + min(ck0 + j, p.cin - 1)];
-                            raw[j] = (bf16_t)((ck0 + j < p.cin) ? z : 0.f);
+                        for (int j = 0; j < 8; ++j) z[j] = act_t<ACT>(fmaf((float)raw[j], psc[j], psh[j]), p.pro.act);
+                        if (p.pro.bscale) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) z[j] *= p.pro.bscale[pb * p.cin + min(ck0 + j, p.cin - 1)];
                         }
+                        if (ck0 + 8 > p.cin) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) if (ck0 + j >= p.cin) z[j] = 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) raw[j] = (bf16_t)z[j];
                     }
                     rx[v] = raw;
                 }

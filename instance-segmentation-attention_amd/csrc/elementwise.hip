@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) 
             load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, v, nv);
             const long bofs = per_image ? (long)((unsigned)pix / hw) * C : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float z = act_t<ACT>(fmaf(v[j], sc[j], sh[j]), p.pro.act);
-                if (p.pro.bscale) z *= p.pro.bscale[bofs + min(c0 + j, C - 1)];
-                v[j] = z;
+            for (int j = 0; j < 8; ++j) v[j] = act_t<ACT>(fmaf(v[j], sc[j], sh[j]), p.pro.act);
+            if (p.pro.bscale) {                              // wave-uniform: not a test per element
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= p.pro.bscale[bofs + min(c0 + j, C - 1)];
             }
             if (p.has_res) {
                 float rr[8];
