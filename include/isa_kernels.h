@@ -382,6 +382,15 @@ int isa_d4_augment(const uint8_t* src, uint8_t* dst, int32_t n, int32_t s, int32
 int isa_resize_nearest_u8(const uint8_t* src, int32_t n, int32_t h0, int32_t w0, int32_t c, uint8_t* dst,
                           int32_t h, int32_t w, void* stream);
 
+/* Bilinear image resize: the `img_resizer` of AlignCollate and Prediction (code/lib/dataset.py:160-161,
+ * 166-167, prediction.py:37 -> utils.py:26-27 -> PIL Image.resize(BILINEAR)) for uint8 images [n,h0,w0,c] (c <= 4) ->
+ * [n,h,w,c], bit-identical to Pillow's Resample.c (anti-aliased triangle filter, 22-bit fixed-point coefficients,
+ * horizontal pass into a uint8 intermediate, then vertical).  ws: device scratch of isa_resize_bilinear_ws_bytes(...)
+ * bytes (coefficient tables + the intermediate image); ISA_ENOMEM when smaller. */
+int64_t isa_resize_bilinear_ws_bytes(int32_t n, int32_t h0, int32_t w0, int32_t c, int32_t h, int32_t w);
+int isa_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t h0, int32_t w0, int32_t c, uint8_t* dst,
+                           int32_t h, int32_t w, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- boundary layout converters (the reference passes NCHW fp32: reseg.py:106-110) ----------- */
 int isa_nchw_to_nhwc(const float* src, int32_t csrc, const isa_tensor* dst, void* stream);
 int isa_nhwc_to_nchw(const isa_tensor* src, float* dst, void* stream);

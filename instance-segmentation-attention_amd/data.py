@@ -79,6 +79,27 @@ def d4_augment(tensors, ops, device="cuda"):
     return out
 
 
+_RESIZE_WS = {}
+
+
+def resize_bilinear(images, size, device="cuda"):
+    """The reference's `img_resizer` (dataset.py:160-161, prediction.py:37: PIL Image.resize(BILINEAR)) on the device:
+    uint8 [n,h0,w0,c] (c <= 4) -> uint8 [n,size_h,size_w,c], bit-identical to Pillow (isa_resize_bilinear_u8)."""
+    from . import lib as L
+    h, w = (size, size) if isinstance(size, int) else size
+    src = images.to(device).contiguous()
+    assert src.dtype == torch.uint8 and src.dim() == 4
+    n, h0, w0, c = src.shape
+    dst = torch.empty((n, h, w, c), dtype=torch.uint8, device=src.device)
+    need = int(L.lib().isa_resize_bilinear_ws_bytes(n, h0, w0, c, h, w))
+    ws = _RESIZE_WS.get(src.device)
+    if ws is None or ws.numel() < need:
+        ws = _RESIZE_WS[src.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=src.device)
+    L.check(L.lib().isa_resize_bilinear_u8(L.ptr(src), n, h0, w0, c, L.ptr(dst), h, w, L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "isa_resize_bilinear_u8")
+    return dst
+
+
 class DevicePrefetcher(object):
     """Wraps an iterable of collated host batches (x, sem, ins, n): batch i+1 travels to the device on its own HIP
     stream while step i computes, so the host-to-device time of the reference's hand-over (373 MB per step at bs=16:

@@ -69,6 +69,7 @@ SIGNATURES = {
     "isa_bn_running_update": [C.POINTER(IsaBnUpd), I32, F, VP],
     "isa_d4_augment": [VP, VP, I32, I32, I32, VP, VP],
     "isa_resize_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP],
+    "isa_resize_bilinear_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP, I64, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],
     "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
@@ -137,6 +138,8 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: intended
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.isa_resize_bilinear_ws_bytes.argtypes = [I32] * 6       # the one entry point that returns a size, not a status
+    lib.isa_resize_bilinear_ws_bytes.restype = C.c_int64
     return lib
 
 

@@ -23,8 +23,9 @@ from pred_list import H, W, nearest_upsample  # noqa: E402
 def predict_file(model, image, out_dir, name):
     """image: uint8 RGB [h0,w0,3].  Returns the path of the written mask."""
     from PIL import Image
-    small = np.asarray(Image.fromarray(image).resize((W, H), Image.BILINEAR))
-    x = torch.from_numpy(small[None]).cuda()                   # uint8 [1,H,W,3]: ImageEx runs on the device
+    from isa_amd.data import resize_bilinear
+    x = resize_bilinear(torch.from_numpy(image[None]), (H, W))  # uint8 [1,H,W,3] on the device, bit-identical to PIL's
+                                                               # BILINEAR resize (prediction.py:37); ImageEx follows there
     net = model.model
     net.eval()
     with torch.no_grad():

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import isa_amd  # noqa: F401,E402
 from isa_amd.model import Model  # noqa: E402
+from isa_amd.data import resize_bilinear  # noqa: E402
 
 H = W = 256                                             # data_settings.py: IMAGE_HEIGHT / IMAGE_WIDTH
 
@@ -68,8 +69,8 @@ def main():
     done = 0
     for s in range(0, len(names), opt.batch):
         imgs = [ld() for ld in loaders[s:s + opt.batch]]
-        small = np.stack([np.asarray(Image.fromarray(im).resize((W, H), Image.BILINEAR)) for im in imgs])
-        x = torch.from_numpy(small).cuda()               # uint8 [B,H,W,3]: ImageEx runs on the device
+        # resize on the device (isa_resize_bilinear_u8, bit-identical to PIL's BILINEAR): one launch per source size
+        x = torch.cat([resize_bilinear(torch.from_numpy(im[None]), (H, W)) for im in imgs])   # uint8 [B,H,W,3]; ImageEx follows
         _, sem_arg = net.infer_graphed(x) if len(imgs) == opt.batch else net(False, x)
         # softmax(l)[1] > 0.5 (pred.py:117-121) is l1 > l0: the arg-max map the library already returns
         fg = (sem_arg[:, 0] > 0.5).to(torch.uint8).cpu().numpy()

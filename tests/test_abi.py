@@ -18,6 +18,10 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name), name
+    sizes = set(re.findall(r"\bint64_t\s+(isa_[a-z0-9_]+)\s*\(", hdr))         # entry points that return a size
+    assert sizes == {"isa_resize_bilinear_ws_bytes"}
+    for name in sizes:
+        assert hasattr(lib, name), name
 
 
 def test_missing_library_fails_loudly(monkeypatch):

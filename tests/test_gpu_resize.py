@@ -47,3 +47,27 @@ def test_invalid_arguments():
     assert f(L.ptr(t), 1, 4, 4, 1, L.ptr(u), 769, 4, L.stream_ptr()) != 0         # table capacity
     assert f(L.ptr(t), 1, 0, 4, 1, L.ptr(u), 4, 4, L.stream_ptr()) != 0
     assert f(None, 1, 4, 4, 1, L.ptr(u), 4, 4, L.stream_ptr()) != 0
+
+
+def test_bilinear_resize_bit_exact_vs_oracle_and_pillow():
+    """isa_resize_bilinear_u8 (the reference's `img_resizer`) against oracle/resize_ref.resize_bilinear (pinned to Pillow
+    on the CPU) and, where Pillow is importable, against PIL.Image.resize(BILINEAR) itself - bit for bit, including
+    CVPPP's 530x500 -> 256x256, up-scaling, unchanged axes and a batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import isa_amd  # noqa: F401
+    from isa_amd.data import resize_bilinear
+    rng = np.random.default_rng(5)
+    cases = [(2, 530, 500, 256, 256), (1, 256, 256, 256, 256), (3, 37, 91, 64, 48), (1, 16, 16, 33, 7), (1, 300, 400, 512, 512),
+             (1, 256, 300, 256, 256), (1, 301, 417, 256, 256), (1, 1024, 768, 256, 256)]
+    cases += [(1,) + tuple(int(v) for v in rng.integers(1, 300, 4)) for _ in range(12)]
+    for (n, h0, w0, h, w) in cases:
+        img = rng.integers(0, 256, (n, h0, w0, 3), dtype=np.uint8)
+        got = resize_bilinear(torch.from_numpy(img), (h, w)).cpu().numpy()
+        np.testing.assert_array_equal(got, R.resize_bilinear(img, h, w), err_msg="%s" % ((n, h0, w0, h, w),))
+        try:
+            from PIL import Image
+            np.testing.assert_array_equal(got[0], np.asarray(Image.fromarray(img[0]).resize((w, h), Image.BILINEAR)))
+        except ImportError:
+            pass

@@ -31,3 +31,21 @@ def test_planes_match_pillow():
             want = np.array(Image.fromarray(planes[:, :, k]).resize((w, h), Image.NEAREST))
             np.testing.assert_array_equal(got[:, :, k], want)
         np.testing.assert_array_equal(R.resize_nearest(planes[:, :, 0], h, w), got[:, :, 0])
+
+
+def test_bilinear_matches_pillow():
+    """oracle/resize_ref.resize_bilinear against PIL.Image.resize(BILINEAR) - the reference's `img_resizer` - bit for
+    bit: CVPPP's 530x500 -> 256x256, up-scaling, identity axes, extreme aspect changes, random sizes."""
+    rng = np.random.default_rng(2)
+    cases = [(530, 500, 256, 256), (256, 256, 256, 256), (37, 91, 64, 48), (16, 16, 33, 7), (300, 400, 512, 512),
+             (1, 9, 4, 3), (1024, 1024, 256, 256), (256, 300, 256, 256), (301, 417, 256, 256)]
+    cases += [tuple(int(v) for v in rng.integers(1, 400, 4)) for _ in range(40)]
+    for (h0, w0, h, w) in cases:
+        img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR))
+        got = R.resize_bilinear(img, h, w)
+        np.testing.assert_array_equal(got, want, err_msg="%dx%d -> %dx%d" % (h0, w0, h, w))
+    # flat and saturated images stay exact (the rounding constant and the clip)
+    for v in (0, 255, 128):
+        img = np.full((50, 70, 3), v, np.uint8)
+        np.testing.assert_array_equal(R.resize_bilinear(img, 31, 17), np.asarray(Image.fromarray(img).resize((17, 31), Image.BILINEAR)))

@@ -36,6 +36,8 @@ parser.add_argument('--size', type=int, default=256, help='image height = width 
 parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
 parser.add_argument('--compact-targets', action='store_true',
                     help='loader yields uint8 targets (sem [B,H,W], ins [B,H,W,32]); expanded on the device')
+parser.add_argument('--data', default='', help='directory holding <data>/training-lmdb and <data>/validation-lmdb record '
+                    'stores (the reference\'s key schema over a directory: isa_amd/records.py); default: synthetic batches')
 parser.add_argument('--out', default=os.path.join(ROOT, 'models', 'CVPPP', 'run'))
 opt = parser.parse_args()
 assert opt.dataset in ['CVPPP', ]
@@ -54,6 +56,12 @@ train_loader = SyntheticLoader(opt.iters_per_epoch, per_rank, opt.size, opt.size
                                compact=opt.compact_targets)
 test_loader = SyntheticLoader(max(1, opt.iters_per_epoch // 4), per_rank, opt.size, opt.size,
                               seed=parallel.rank_seed(SEED + 7, rank), compact=opt.compact_targets)
+if opt.data:                      # the reference's datasets (train.py:87-147): records -> device-side collate
+    from isa_amd.records import RecordDataset, RecordLoader
+    train_loader = RecordLoader(RecordDataset(os.path.join(opt.data, 'training-lmdb')), per_rank, opt.size, opt.size,
+                                mode='training', seed=SEED, rank=rank, world=world)
+    test_loader = RecordLoader(RecordDataset(os.path.join(opt.data, 'validation-lmdb')), per_rank, opt.size, opt.size,
+                               mode='test', seed=SEED, rank=rank, world=world)
 model.fit('Multi', 0.5, 1.5, 2, 1.0, 0.001, 10.0, 0.5, 25, False, 'Adadelta', True, opt.nepochs, None,
           train_loader, test_loader, opt.out, opt.debug)
 if world > 1:
