@@ -14,6 +14,14 @@
 
 namespace {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL stores (vmcnt(0)
+// ahead of s_barrier): in the persistent tile loops below that exposed the latency of the output stores once per tile.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int TH = 8, TW = 32, CB = 32, PS = 36;         // tile rows/cols, channel block, pixel stride (floats)
 constexpr int HALO = (TH + 2) * (TW + 2);
 
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
         while (ti.valid()) {
             ti.next();                                           // the tile the compute waves will consume next
             if (ti.valid()) stage(ti.b, ti.ty, ti.tx, tile_base + (buf ^ 1) * HALO * PS);
-            __syncthreads();
+            lds_barrier();
             buf ^= 1;
         }
     } else {
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
             __syncthreads();
             for (; ti.valid(); ti.next()) {
                 compute(ti.b, ti.ty, ti.tx, tile_base + buf * HALO * PS, s1, s2);
-                __syncthreads();
+                lds_barrier();
                 buf ^= 1;
             }
         } else {
@@ -607,6 +615,60 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             const int rr = hrc[it] >> 16, cc = hrc[it] & 0xffff;
             okk[it] = hok[it] && (interior || (rr >= rlo && rr < rhi && cc >= clo && cc < chi));
         }
+        // All 16-byte loads of the tile (g, y and x: 3 x NIT per lane) are issued back to back BEFORE any arithmetic.
+        // Ablation at 256x256x64: removing the loads took 223 -> 120 us, removing both stencils only 223 -> 201 us: the
+        // staging chain (wait for g/y, arithmetic, wait for x, arithmetic) is the tile period, so its two exposed
+        // memory latencies become one.  (f32 storage keeps chunks of NB = 3 loads: registers.)
+        if constexpr (DB) {
+            raw8<T> gv[NIT], yv[NIT], xv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (okk[it]) {
+                    gv[it].load(gb + hog[it]);
+                    yv[it].load(yb + hoy[it]);
+                    xv[it].load(xb + hox[it]);
+                }
+            }
+            float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
+            ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
+            ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = (ltid + it * 256) >> 2;
+                if (pix >= HALO) continue;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                if (okk[it]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yy = yv[it].get(j);
+                        const float z = fmaf(yy, sc[j], sh[j]);
+                        const float dz = gv[it].get(j) * act_grad_t<YACT>(z, p.yact);
+                        const float yh = (yy - mu[j]) * is[j];
+                        o[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
+                    }
+                }
+                store8<T>(dt + pix * PSD + cg * 8, o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float xs[8], xh[8];
+            ld8(cst + 6 * CB + cg * 8, xs); ld8(cst + 7 * CB + cg * 8, xh);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = (ltid + it * 256) >> 2;
+                if (pix >= HALO) continue;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                if (okk[it]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = XMODE ? act_t<XACT>(fmaf(xv[it].get(j), xs[j], xh[j]), p.xact) : xv[it].get(j);
+                }
+                store8<float>(xt + pix * PS + cg * 8, o);
+            }
+        } else {
         {   // ---- dy = BN-backward(g, y) with halo
             float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
             ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
@@ -668,6 +730,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
     };
 
@@ -776,7 +839,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         while (ti.valid()) {
             ti.next();                                           // the tile the compute waves consume next
             if (ti.valid()) stage(ti.b, ti.ty, ti.tx, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
-            __syncthreads();
+            lds_barrier();
             buf ^= 1;
         }
     } else {
@@ -793,7 +856,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             __syncthreads();                                     // first tile staged
             for (; ti.valid(); ti.next()) {
                 compute(ti.b, ti.ty, ti.tx, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
-                __syncthreads();
+                lds_barrier();
                 buf ^= 1;
             }
         } else {

@@ -77,6 +77,11 @@ class Act:
         return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
 
 
+# ISA_ARENA_POISON=1 (debug / tests): every arena buffer that is handed out un-zeroed, and the slab arena, are filled with
+# 0xFF bytes each step, so any read of memory the step itself did not write turns into NaN instead of stale values.
+POISON = os.environ.get("ISA_ARENA_POISON", "0") == "1"
+
+
 class Arena:
     """Bump allocator whose allocations are replayed in the same order every step.  One arena per
     configuration (Engine.begin's key): a captured hipGraph holds raw pointers into its arena, so the
@@ -120,6 +125,8 @@ class Arena:
         self.cursor += 1
         if zero:
             t.zero_()
+        elif POISON:
+            t.view(torch.uint8).fill_(0xFF)        # NaN in every float type: a kernel that reads what no kernel wrote shows up
         return t
 
     def scratch(self, numel) -> torch.Tensor:
@@ -501,6 +508,8 @@ class Engine:
             arena = self.arenas[akey] = Arena(self.device)
         self.arena = arena
         arena.reset()
+        if POISON:
+            self.ws.view(torch.uint8).fill_(0xFF)
         self.grads.reset()
         self.tape = Tape(self)
         self.cur = 0
@@ -1019,6 +1028,8 @@ class Engine:
                     "isa_slab_arena_create")
             self.slab = h
         L.check(self.lib.isa_slab_arena_begin(self.slab), "isa_slab_arena_begin")
+        if POISON:
+            self.fold_arena.view(torch.uint8).fill_(0xFF)
         self._deferring = True
         try:
             for fn, tag in reversed(self.tape):
