@@ -11,6 +11,7 @@
 //   * wgrad: persistent over tiles of one channel block; 9x8 products per lane accumulated in registers
 //     across tiles, reduced once (shuffle tree + LDS) into a per-workgroup slab (no global atomics).
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -40,11 +41,15 @@ template <> struct raw8<bf16_t> {
     bf16x8 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
     __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    __device__ __forceinline__ void zero() { v = bf16x8{}; }
 };
 template <> struct raw8<float> {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
     __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+    __device__ __forceinline__ void zero() { a = f32x4{}; b = f32x4{}; }
 };
 
 // per-lane prologue constants: a lane stages the same 8-channel group on every iteration (i += 256 keeps i & 3)
@@ -532,24 +537,36 @@ struct FusedParams {
 template <typename T> struct dd_stride { static constexpr int v = 36; };       // floats: 144 B / pixel
 template <> struct dd_stride<bf16_t> { static constexpr int v = 40; };         // 80 B / pixel: 4 x-groups tile 256 B
 
-// DB (bf16): 512 threads, two LDS tile buffers.  Waves 4-7 only stage the NEXT tile (all of its 16-byte loads in
-// flight at once, BN-backward / prologue arithmetic, LDS stores) while waves 0-3 run the two stencils on the
-// current one; one __syncthreads per tile swaps the buffers.  The single-buffer form (f32 storage: the tiles do
-// not fit twice) runs the same phases back to back in 256 threads.  Measured on the 256x256x64 level: PMC showed
-// the single-buffer kernel waiting on memory for most of each tile (2 waves/SIMD, phases serialised).
-template <typename T, int YACT, int XMODE, bool DB>
+// DB (bf16): 512 threads, two LDS tile buffers.  Waves 4-7 (loader role) only stage tiles - 16-byte loads, the
+// BN-backward arithmetic of dy, LDS stores - while waves 0-3 (compute role) run the two stencils on the current tile;
+// one LDS-only barrier per tile swaps the buffers.  The single-buffer form (f32 storage: the tiles do not fit twice)
+// runs the same phases back to back in 256 threads.
+// What the measurements said (256x256x64, bf16, 223 us at the start):
+//  * PMC: the single-buffer kernel waited on memory for most of each tile -> the role split.
+//  * Ablation: no loads 120 us, no loader arithmetic 184 us, no stencils 201 us - every part additive.
+//  * A cycle trace of one workgroup: the COMPUTE wave was the critical path.  Its epilogue loaded raw x (for the
+//    BN(x) sums) from global memory, and those few loads queued in the CU's in-order vector-memory pipeline behind the
+//    loader's bulk stream: every tile waited most of a tile's HBM time for them, the loader idled at the barrier.
+//  -> the LDS tile now holds RAW x (storage type).  The compute role applies the lazy prologue itself (the unfused
+//     arithmetic, bit for bit), takes the centre pixels for the BN(x) sums from the same tile and, in the common case,
+//     reads no global memory at all.  LDS drops from 152 to 109 KB and the weight-gradient window reads halve.
+//  -> the loader is software-pipelined across tiles (a tile's worth of loads always in flight) and keeps its
+//     per-channel constants in registers: it is VALU-issue bound next to the compute wave of the same SIMD.
+// EPI: the tile epilogue has extra operands (accumulate into old dx and / or a residual addend): rare, so the common
+// variant compiles their loads and registers out.
+template <typename T, int YACT, int XMODE, bool DB, bool EPI>
 __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_bn_bwd_kernel(FusedParams p) {
     constexpr int PSD = dd_stride<T>::v;
     constexpr int XACT = XMODE == 1 ? ISA_ACT_RELU6 : (XMODE == 0 ? ISA_ACT_NONE : ACT_RT);
     constexpr int NBUF = DB ? 2 : 1;
     constexpr int NTHR = DB ? 512 : 256;
-    constexpr int XT_FLOATS = HALO * PS, DT_ELEMS = HALO * PSD;
+    constexpr int TILE_ELEMS = HALO * PSD;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xt_base = sm;                                                     // [NBUF][HALO][PS]  pro(x), fp32
-    T* dt_base = reinterpret_cast<T*>(sm + NBUF * XT_FLOATS);                // [NBUF][HALO][PSD] dy, storage type
-    float* wts = reinterpret_cast<float*>(dt_base + NBUF * DT_ELEMS);        // [9][CB] flipped taps
+    T* xt_base = reinterpret_cast<T*>(sm);                                   // [NBUF][HALO][PSD] RAW x (0 outside the image)
+    T* dt_base = xt_base + NBUF * TILE_ELEMS;                                // [NBUF][HALO][PSD] dy
+    float* wts = reinterpret_cast<float*>(dt_base + NBUF * TILE_ELEMS);      // [9][CB] flipped taps
     float* cst = wts + 9 * CB;                                               // [10][CB] per-channel constants
-    float* red = cst + 10 * CB;                                              // [10*CB]
+    float* red = cst + 10 * CB;                                              // [11*CB]
     const int tid = threadIdx.x;
     const int ltid = tid & 255;                                              // index inside the role group
     const bool loader = DB && tid >= 256;
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const T* xin = reinterpret_cast<const T*>(p.x);
     T* dxo = reinterpret_cast<T*>(p.dx);
     constexpr int NIT = (HALO * 4 + 255) / 256;
-    constexpr int NB = DB ? NIT : 3;                 // loader waves own their registers: a whole tile in flight
+    constexpr int NB = 3;                            // single-buffer form: loads in chunks of 3 slots (registers)
     static_assert(NIT % NB == 0, "staging chunks");
     const bool want_xred = XMODE == 1 || (XMODE == 2 && p.xred != nullptr);
 
@@ -602,154 +619,94 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         hox[it] = (rr * p.w_ + cc) * p.ldx + cc0;
         hok[it] = pix < HALO && cok;
     }
-    const int oox = (row * p.w_ + x0) * p.ldx + c0, oodx = (row * p.w_ + x0) * p.lddx + c0, ooa = (row * p.w_ + x0) * p.lda + c0;
+    const int oodx = (row * p.w_ + x0) * p.lddx + c0, ooa = (row * p.w_ + x0) * p.lda + c0;
 
-    auto stage = [&](int b, int ty, int tx, float* xt, T* dt) {
+    // ---- per-tile geometry shared by both staging forms
+    struct Geo { const T *gb, *yb, *xb; int rlo, rhi, clo, chi, sg, sy, sx; bool interior; };
+    auto geo = [&](int b, int ty, int tx) {
+        Geo g;
         const long horg = ((long)b * p.h + ty * TH - 1) * p.w_ + tx * TW - 1;           // halo origin pixel (may lie outside)
-        const T* gb = gin + horg * p.ldg; const T* yb = yin + horg * p.ldy; const T* xb = xin + horg * p.ldx;
-        const int rlo = 1 - ty * TH, rhi = p.h + 1 - ty * TH, clo = 1 - tx * TW, chi = p.w_ + 1 - tx * TW;
-        const bool interior = rlo <= 0 && rhi >= TH + 2 && clo <= 0 && chi >= TW + 2;
-        bool okk[NIT];
+        g.gb = gin + horg * p.ldg; g.yb = yin + horg * p.ldy; g.xb = xin + horg * p.ldx;
+        g.rlo = 1 - ty * TH; g.rhi = p.h + 1 - ty * TH; g.clo = 1 - tx * TW; g.chi = p.w_ + 1 - tx * TW;
+        g.interior = g.rlo <= 0 && g.rhi >= TH + 2 && g.clo <= 0 && g.chi >= TW + 2;
+        const int cc0 = cok ? c0 : c_base;
+        g.sg = (p.w_ + 1) * p.ldg + cc0; g.sy = (p.w_ + 1) * p.ldy + cc0; g.sx = (p.w_ + 1) * p.ldx + cc0;   // halo (1,1) = tile origin
+        return g;
+    };
+    auto slot_ok = [&](const Geo& g, int it) {
+        const int rr = hrc[it] >> 16, cc = hrc[it] & 0xffff;
+        return hok[it] && (g.interior || (rr >= g.rlo && rr < g.rhi && cc >= g.clo && cc < g.chi));
+    };
+    // per-channel constants of the staging arithmetic: tile-invariant, so they live in registers for the whole kernel
+    struct StageK { float sc[8], sh[8], mu[8], is[8], k0[8], k1[8]; };
+    // one halo slot: dy = BN-backward(g, y) and raw x, both as storage type into the LDS tiles
+    auto convert = [&](bool ok, int it, const StageK& K, const raw8<T>& gv, const raw8<T>& yv, const raw8<T>& xv, T* xt, T* dt) {
+        const int pix = (ltid + it * 256) >> 2;
+        if (pix >= HALO) return;
+        float o[8];
+        raw8<T> q = xv;                                           // raw x travels as it is: 16 bytes, no conversion
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int rr = hrc[it] >> 16, cc = hrc[it] & 0xffff;
-            okk[it] = hok[it] && (interior || (rr >= rlo && rr < rhi && cc >= clo && cc < chi));
+        for (int j = 0; j < 8; ++j) {
+            const float yy = yv.get(j);
+            const float z = fmaf(yy, K.sc[j], K.sh[j]);
+            const float dz = gv.get(j) * act_grad_t<YACT>(z, p.yact);
+            const float yh = (yy - K.mu[j]) * K.is[j];
+            o[j] = K.sc[j] * (dz - K.k0[j] - yh * K.k1[j]);
         }
-        // All 16-byte loads of the tile (g, y and x: 3 x NIT per lane) are issued back to back BEFORE any arithmetic.
-        // Ablation at 256x256x64: removing the loads took 223 -> 120 us, removing both stencils only 223 -> 201 us: the
-        // staging chain (wait for g/y, arithmetic, wait for x, arithmetic) is the tile period, so its two exposed
-        // memory latencies become one.  (f32 storage keeps chunks of NB = 3 loads: registers.)
-        if constexpr (DB) {
-            raw8<T> gv[NIT], yv[NIT], xv[NIT];
+        // out-of-image halo slots were fetched from the tile's origin pixel: zero them.  Interior tiles have none and the
+        // test is uniform over the wave there, so the 16 selects are skipped
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (okk[it]) {
-                    gv[it].load(gb + hog[it]);
-                    yv[it].load(yb + hoy[it]);
-                    xv[it].load(xb + hox[it]);
-                }
-            }
-            float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
-            ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
-            ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
+            for (int j = 0; j < 8; ++j) o[j] = ok ? o[j] : 0.f;
+            if (!ok) q.zero();
+        }
+        store8<T>(dt + pix * PSD + cg * 8, o);
+        q.store(xt + pix * PSD + cg * 8);
+    };
+    // Loads are unconditional (clamped address) so a chunk loop is straight-line code.  The empty asm keeps them where
+    // they are written: LLVM otherwise sinks a prefetch down to its first use - across the LDS-only barrier and the loop
+    // back-edge, into the `ok` branch - which undoes it and turns every partial vmcnt wait into a full one.
+    auto issue = [&](const Geo& g, int it, raw8<T>& gv, raw8<T>& yv, raw8<T>& xv) {
+        const bool ok = slot_ok(g, it);
+        gv.load(g.gb + (ok ? hog[it] : g.sg));
+        yv.load(g.yb + (ok ? hoy[it] : g.sy));
+        xv.load(g.xb + (ok ? hox[it] : g.sx));
+        asm volatile("" ::: "memory");
+    };
+
+    // single-buffer form: one tile, chunks of NB slots
+    auto stage = [&](int b, int ty, int tx, T* xt, T* dt) {
+        const Geo g = geo(b, ty, tx);
+        StageK K;                                                 // per tile here: these threads also hold the accumulators
+        ld8(cst + 0 * CB + cg * 8, K.sc); ld8(cst + 1 * CB + cg * 8, K.sh); ld8(cst + 2 * CB + cg * 8, K.mu);
+        ld8(cst + 3 * CB + cg * 8, K.is); ld8(cst + 4 * CB + cg * 8, K.k0); ld8(cst + 5 * CB + cg * 8, K.k1);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = (ltid + it * 256) >> 2;
-                if (pix >= HALO) continue;
-                float o[8];
+        for (int it0 = 0; it0 < NIT; it0 += NB) {
+            raw8<T> gv[NB], yv[NB], xv[NB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                if (okk[it]) {
+            for (int u = 0; u < NB; ++u) issue(g, it0 + u, gv[u], yv[u], xv[u]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float yy = yv[it].get(j);
-                        const float z = fmaf(yy, sc[j], sh[j]);
-                        const float dz = gv[it].get(j) * act_grad_t<YACT>(z, p.yact);
-                        const float yh = (yy - mu[j]) * is[j];
-                        o[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
-                    }
-                }
-                store8<T>(dt + pix * PSD + cg * 8, o);
-            }
+            for (int u = 0; u < NB; ++u) convert(slot_ok(g, it0 + u), it0 + u, K, gv[u], yv[u], xv[u], xt, dt);
             __builtin_amdgcn_sched_barrier(0);
-            float xs[8], xh[8];
-            ld8(cst + 6 * CB + cg * 8, xs); ld8(cst + 7 * CB + cg * 8, xh);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = (ltid + it * 256) >> 2;
-                if (pix >= HALO) continue;
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                if (okk[it]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        o[j] = XMODE ? act_t<XACT>(fmaf(xv[it].get(j), xs[j], xh[j]), p.xact) : xv[it].get(j);
-                }
-                store8<float>(xt + pix * PS + cg * 8, o);
-            }
-        } else {
-        {   // ---- dy = BN-backward(g, y) with halo
-            float sc[8], sh[8], mu[8], is[8], k0[8], k1[8];
-            ld8(cst + 0 * CB + cg * 8, sc); ld8(cst + 1 * CB + cg * 8, sh); ld8(cst + 2 * CB + cg * 8, mu);
-            ld8(cst + 3 * CB + cg * 8, is); ld8(cst + 4 * CB + cg * 8, k0); ld8(cst + 5 * CB + cg * 8, k1);
-#pragma unroll
-            for (int it0 = 0; it0 < NIT; it0 += NB) {
-                raw8<T> gv[NB], yv[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    if (okk[it0 + u]) {
-                        gv[u].load(gb + hog[it0 + u]);
-                        yv[u].load(yb + hoy[it0 + u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int pix = (ltid + (it0 + u) * 256) >> 2;
-                    if (pix >= HALO) continue;
-                    float o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                    if (okk[it0 + u]) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float yy = yv[u].get(j);
-                            const float z = fmaf(yy, sc[j], sh[j]);
-                            const float dz = gv[u].get(j) * act_grad_t<YACT>(z, p.yact);
-                            const float yh = (yy - mu[j]) * is[j];
-                            o[j] = sc[j] * (dz - k0[j] - yh * k1[j]);
-                        }
-                    }
-                    store8<T>(dt + pix * PSD + cg * 8, o);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        {   // ---- pro(x) with halo (fp32)
-            float sc[8], sh[8];
-            ld8(cst + 6 * CB + cg * 8, sc); ld8(cst + 7 * CB + cg * 8, sh);
-#pragma unroll
-            for (int it0 = 0; it0 < NIT; it0 += NB) {
-                raw8<T> xv[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u)
-                    if (okk[it0 + u]) xv[u].load(xb + hox[it0 + u]);
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int pix = (ltid + (it0 + u) * 256) >> 2;
-                    if (pix >= HALO) continue;
-                    float o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                    if (okk[it0 + u]) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            o[j] = XMODE ? act_t<XACT>(fmaf(xv[u].get(j), sc[j], sh[j]), p.xact) : xv[u].get(j);
-                    }
-                    store8<float>(xt + pix * PS + cg * 8, o);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
         }
     };
 
-    auto compute = [&](int b, int ty, int tx, const float* xt, const T* dt, float (&acc)[9][8], float (&s0)[8], float (&s1)[8]) {
+    auto compute = [&](int b, int ty, int tx, const T* xt, const T* dt, float (&acc)[9][8], float (&s0)[8], float (&s1)[8]) {
         const long torg = ((long)b * p.h + ty * TH) * p.w_ + tx * TW;                      // tile origin pixel
-        const T* xo = xin + torg * p.ldx + oox; T* dxb = dxo + torg * p.lddx + oodx;
+        T* dxb = dxo + torg * p.lddx + oodx;
         const T* adb = reinterpret_cast<const T*>(p.addend) + torg * p.lda + ooa;
         const bool rowok = ty * TH + row < p.h && cok;
         const int xlim = p.w_ - tx * TW;                                                   // x0 + o < xlim
-        // operands of the epilogue (old dx for accumulate, raw x for the BN(x) sums) are requested before the
-        // stencil so their latency hides behind it: a compute wave has no sibling wave to switch to
-        raw8<T> xc[4], oc[4], ad[4];
-        if (rowok) {
+        // rare epilogue operands (old dx for accumulate, the residual addend): requested before the stencil
+        raw8<T> oc[4], ad[4];
+        if constexpr (EPI) {
+            if (rowok) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                if (x0 + o >= xlim) continue;
-                if (want_xred) xc[o].load(xo + o * p.ldx);
-                if (p.accumulate) oc[o].load(dxb + o * p.lddx);
-                if constexpr (XMODE == 0) { if (p.addend) ad[o].load(adb + o * p.lda); }
+                for (int o = 0; o < 4; ++o) {
+                    if (x0 + o >= xlim) continue;
+                    if (p.accumulate) oc[o].load(dxb + o * p.lddx);
+                    if constexpr (XMODE == 0) { if (p.addend) ad[o].load(adb + o * p.lda); }
+                }
             }
         }
         {   // ---- data gradient: dx tile = flipped taps over dy (halo), then BN(x)-backward sums
@@ -781,22 +738,23 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 for (int o = 0; o < 4; ++o) {
                     if (x0 + o >= xlim) continue;
                     T* dst = dxb + o * p.lddx;
-                    if (p.accumulate) {
+                    if constexpr (EPI) {
+                        if (p.accumulate) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[o][j] += oc[o].get(j);
-                    }
-                    if constexpr (XMODE == 0) {              // plain-tensor input: the only case with a residual branch
-                        if (p.addend) {
+                            for (int j = 0; j < 8; ++j) a[o][j] += oc[o].get(j);
+                        }
+                        if constexpr (XMODE == 0) {          // plain-tensor input: the only case with a residual branch
+                            if (p.addend) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) a[o][j] += ad[o].get(j);
+                                for (int j = 0; j < 8; ++j) a[o][j] += ad[o].get(j);
+                            }
                         }
                     }
                     store8<T>(dst, a[o]);
                     if (want_xred) {
                         // the unfused reduce reads the stored (rounded) gradient: round the same way
                         float xr[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xr[j] = xc[o].get(j);
+                        load8<T>(xt + ((row + 1) * (TW + 2) + x0 + 1 + o) * PSD + cg * 8, xr);      // raw x, centre pixel
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float gq = (float)(T)a[o][j];
@@ -813,18 +771,44 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             float d[4][8];
 #pragma unroll
             for (int o = 0; o < 4; ++o) load8<T>(dt + ((row + 1) * (TW + 2) + x0 + 1 + o) * PSD + cg * 8, d[o]);
+            float ps[8], ph[8];
+            if constexpr (XMODE != 0) { ld8(cst + 6 * CB + cg * 8, ps); ld8(cst + 7 * CB + cg * 8, ph); }
+            // Zero padding applies to pro(x), not to x: on border tiles the out-of-image window slots are masked after
+            // the prologue.  Two copies of the stencil behind a uniform branch - as one body with per-slot predicates
+            // the 18 lane masks stayed live across the loop and the accumulators spilled.
+            const int rlo = 1 - ty * TH, rhi = p.h + 1 - ty * TH, clo = 1 - tx * TW, chi = p.w_ + 1 - tx * TW;
+            const bool interior = XMODE == 0 || (rlo <= 0 && rhi >= TH + 2 && clo <= 0 && chi >= TW + 2);
+            auto window = [&](auto border) {
+                constexpr bool BORDER = decltype(border)::value;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float in[6][8];
+                for (int dy = 0; dy < 3; ++dy) {
+                    const bool row_in = row + dy >= rlo && row + dy < rhi;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) ld8(xt + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+                    for (int k = 0; k < 6; ++k) {                // one window pixel at a time: 8 live registers, not 48
+                        float in[8];
+                        load8<T>(xt + ((row + dy) * (TW + 2) + x0 + k) * PSD + cg * 8, in);
+                        if constexpr (XMODE != 0) {
+                            float z[8];
 #pragma unroll
-                for (int o = 0; o < 4; ++o)
+                            for (int j = 0; j < 8; ++j) z[j] = ph[j];
+                            fma8(in, ps, z);                     // packed fma; the clamp has no packed form
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        fma8(in[o + k], d[o], acc[dy * 3 + k]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                            for (int j = 0; j < 8; ++j) in[j] = act_t<XACT>(z[j], p.xact);
+                            if constexpr (BORDER) {
+                                const bool in_img = row_in && x0 + k >= clo && x0 + k < chi;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) in[j] = in_img ? in[j] : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int o = 0; o < 4; ++o)
+                            if (k - o >= 0 && k - o < 3) fma8(in, d[o], acc[dy * 3 + (k - o)]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (interior) window(std::false_type{});
+            else window(std::true_type{});
         }
     };
 
@@ -832,16 +816,45 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // max(loader set, compute set) instead of their sum.  Both sides execute the same number of barriers.
     __syncthreads();                                             // constants + zeroed `red` visible
     if (loader) {
-        TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
+        // Software-pipelined across tiles: the loads of the tile after next are issued chunk by chunk WHILE the next tile
+        // is converted - a chunk's registers are refilled right after its arithmetic consumed them, so a tile's worth of
+        // 16-byte loads (3 x NIT per lane) is always in flight and a chunk only waits for loads issued a tile earlier.
+        // Barriers: one per staged tile (the first is the compute side's "first tile staged", every later one closes the
+        // compute side's previous tile) plus one closing its last tile: n + 1 on both sides.  The steady branch is
+        // straight-line code with the same loads in flight at its top and bottom, so its vmcnt waits stay partial.
+        StageK K;
+        ld8(cst + 0 * CB + cg * 8, K.sc); ld8(cst + 1 * CB + cg * 8, K.sh); ld8(cst + 2 * CB + cg * 8, K.mu);
+        ld8(cst + 3 * CB + cg * 8, K.is); ld8(cst + 4 * CB + cg * 8, K.k0); ld8(cst + 5 * CB + cg * 8, K.k1);
+        TileIter tn; tn.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);     // the tile whose loads are in flight
+        raw8<T> gv[NIT], yv[NIT], xv[NIT];
+        Geo gs, gn;
+        bool have = tn.valid();
+        if (have) {
+            gn = geo(tn.b, tn.ty, tn.tx);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) issue(gn, it, gv[it], yv[it], xv[it]);
+        }
         int buf = 0;
-        if (ti.valid()) stage(ti.b, ti.ty, ti.tx, xt_base, dt_base);
-        __syncthreads();                                         // first tile staged
-        while (ti.valid()) {
-            ti.next();                                           // the tile the compute waves consume next
-            if (ti.valid()) stage(ti.b, ti.ty, ti.tx, xt_base + (buf ^ 1) * XT_FLOATS, dt_base + (buf ^ 1) * DT_ELEMS);
+        while (have) {
+            gs = gn;
+            tn.next();
+            T* xt = xt_base + buf * TILE_ELEMS; T* dt = dt_base + buf * TILE_ELEMS;
+            if (tn.valid()) {
+                gn = geo(tn.b, tn.ty, tn.tx);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    convert(slot_ok(gs, it), it, K, gv[it], yv[it], xv[it], xt, dt);
+                    issue(gn, it, gv[it], yv[it], xv[it]);         // refill the chunk's registers: the tile after this one
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) convert(slot_ok(gs, it), it, K, gv[it], yv[it], xv[it], xt, dt);
+                have = false;
+            }
             lds_barrier();
             buf ^= 1;
         }
+        lds_barrier();
     } else {
         float acc[9][8], s0[8], s1[8];
 #pragma unroll
@@ -853,9 +866,9 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         if constexpr (DB) {
             TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
             int buf = 0;
-            __syncthreads();                                     // first tile staged
+            lds_barrier();                                       // first tile staged
             for (; ti.valid(); ti.next()) {
-                compute(ti.b, ti.ty, ti.tx, xt_base + buf * XT_FLOATS, dt_base + buf * DT_ELEMS, acc, s0, s1);
+                compute(ti.b, ti.ty, ti.tx, xt_base + buf * TILE_ELEMS, dt_base + buf * TILE_ELEMS, acc, s0, s1);
                 lds_barrier();
                 buf ^= 1;
             }
@@ -902,18 +915,21 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <typename T, int YACT, int XMODE>
+template <typename T, int YACT, int XMODE, bool EPI = true>
 int launch_fused_inst(FusedParams& p, dim3 grid, hipStream_t s) {
-    constexpr bool DB = sizeof(T) == 2;                          // two tile buffers fit in 160 KB only for bf16
+    constexpr bool DB = sizeof(T) == 2;                          // two pairs of tile buffers: 109 KB for bf16, 196 KB for f32
+    if constexpr (EPI) {
+        if (!p.accumulate && !p.addend) return launch_fused_inst<T, YACT, XMODE, false>(p, grid, s);
+    }
     constexpr int NBUF = DB ? 2 : 1;
-    constexpr size_t lds = NBUF * ((size_t)HALO * PS * 4 + (size_t)HALO * dd_stride<T>::v * sizeof(T)) + (9 + 10 + 11) * CB * 4;
+    constexpr size_t lds = NBUF * 2 * (size_t)HALO * dd_stride<T>::v * sizeof(T) + (9 + 10 + 11) * CB * 4;   // raw x + dy tiles
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bn_bwd_kernel<T, YACT, XMODE, DB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bn_bwd_kernel<T, YACT, XMODE, DB, EPI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISA_ELAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((dw_bn_bwd_kernel<T, YACT, XMODE, DB>), grid, dim3(DB ? 512 : 256), lds, s, p);
+    hipLaunchKernelGGL((dw_bn_bwd_kernel<T, YACT, XMODE, DB, EPI>), grid, dim3(DB ? 512 : 256), lds, s, p);
     return ISA_OK;
 }
 

@@ -24,6 +24,8 @@ def main(dtype=torch.bfloat16, which=None):
     B = 16
     rows = []
     shapes = [(256, 32), (256, 64), (128, 128), (64, 256), (16, 1024)]
+    if os.environ.get("KBENCH_SHAPES"):            # e.g. KBENCH_SHAPES=256x64,128x128
+        shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["KBENCH_SHAPES"].split(",")]
     for hw, c in shapes:
         schema = [("w", (c, c, 1, 1)), ("wd", (c, 1, 3, 3)), ("bn.weight", (c,)), ("bn.bias", (c,)),
                   ("bn.running_mean", (c,)), ("bn.running_var", (c,)), ("bn.num_batches_tracked", ())]
