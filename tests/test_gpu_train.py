@@ -98,7 +98,7 @@ def _check_gradients(m, z64, z32, label, rerun=None):
     for k, (e, f, n_mine, n_ref) in stats.items():
         # + 5e-3: the size of ONE threshold flip as the reference's own fp32 run shows it where it has one (5e-3 .. 9e-3);
         # the last decoder level has no flip in the reference's fp32 run (floor 6e-5), the HIP run lands one there in
-        # about one process in thirty (scripts/gradflake.py), identically in all three repeats
+        # about one process in thirty, identically in all three repeats
         bound = 4.0 * max(down_floor[k], jitter[k]) + 5e-3
         rows.append((e / bound, k, e, f))
         if e > bound or abs(n_mine - n_ref) > bound * n_ref:      # samples, and the norm of the WHOLE tensor
