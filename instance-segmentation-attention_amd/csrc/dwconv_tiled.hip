@@ -23,6 +23,16 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Sum over the four lanes of a 16-lane row that share (lane & 3): two DPP row rotations, no LDS traffic.  The end-of-
+// kernel folds used a 4-step __shfl_xor tree (ds_bpermute: an LDS round trip per step, dependent) per value: a phase
+// trace of dw_bn_bwd on a one-tile problem showed 26 k of the launch's 47 k cycles in that fold.  Lanes 0-3 of every
+// row then issue the LDS atomic (16 lanes per wave instead of 4, the same number of instructions).
+__device__ __forceinline__ float row_fold4(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8
+    return v;
+}
+
 constexpr int TH = 8, TW = 32, CB = 32, PS = 36;         // tile rows/cols, channel block, pixel stride (floats)
 constexpr int HALO = (TH + 2) * (TW + 2);
 
@@ -350,10 +360,9 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
             // lanes with equal (lane & 3) share a channel group: fold the 16 of them, then 4 LDS atomics per wave
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int off = 4; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+                s1[j] = row_fold4(s1[j]); s2[j] = row_fold4(s2[j]);
             }
-            if ((tid & 63) < 4) {
+            if ((tid & 15) < 4) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { atomicAdd(&red[cg * 8 + j], s1[j]); atomicAdd(&red[CB + cg * 8 + j], s2[j]); }
             }
@@ -431,9 +440,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = tp < 9 ? acc[tp < 9 ? tp : 0][j] : db[j];
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+            v = row_fold4(v);
+            if ((tid & 15) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
         }
     }
     __syncthreads();
@@ -881,25 +889,36 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 __syncthreads();                                 // tile fully consumed before it is restaged
             }
         }
-        // fold this lane's sums: 16 lanes share a channel group, then 4 LDS atomics per wave and value
+        // Fold this lane's 88 sums WITHOUT atomics (a phase trace of a one-tile launch: 26 k of its 47 k cycles sat in the
+        // old fold - a ds_bpermute tree per value plus same-address LDS float atomics from four waves).  Row sums by
+        // DPP, then the 16 rows of the 4 compute waves park their partials in the (now idle) tile buffers:
+        // part[(v * 4 + cg) * 16 + wave * 4 + row]; 352 threads add 16 partials each after the barrier below.
+        float* part = reinterpret_cast<float*>(sm);
+        const int slot = cg * 16 + (tid >> 6) * 4 + ((tid >> 4) & 3);
+        const bool writer = (tid & 15) < 4;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = acc[tp][j];
-#pragma unroll
-                for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-                if ((tid & 63) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
+                const float v = row_fold4(acc[tp][j]);
+                if (writer) part[(tp * 8 + j) * 64 + slot] = v;
             }
         }
-        if (want_xred) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v0 = s0[j], v1 = s1[j];
-#pragma unroll
-                for (int off = 4; off < 64; off <<= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
-                if ((tid & 63) < 4) { atomicAdd(&red[9 * CB + cg * 8 + j], v0); atomicAdd(&red[10 * CB + cg * 8 + j], v1); }
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float v0 = row_fold4(s0[j]), v1 = row_fold4(s1[j]);
+            if (writer) { part[(72 + j) * 64 + slot] = v0; part[(80 + j) * 64 + slot] = v1; }
+        }
+    }
+    __syncthreads();
+    {
+        const float* part = reinterpret_cast<const float*>(sm);
+        for (int o = tid; o < 88 * 4; o += NTHR) {               // o = v * 4 + cg
+            const f32x4 a = *reinterpret_cast<const f32x4*>(part + o * 16), b = *reinterpret_cast<const f32x4*>(part + o * 16 + 4),
+                        c = *reinterpret_cast<const f32x4*>(part + o * 16 + 8), d = *reinterpret_cast<const f32x4*>(part + o * 16 + 12);
+            const f32x4 t = (a + b) + (c + d);
+            const int v = o >> 2, g = o & 3;
+            red[(v >> 3) * CB + g * 8 + (v & 7)] = (t[0] + t[1]) + (t[2] + t[3]);
         }
     }
     __syncthreads();
