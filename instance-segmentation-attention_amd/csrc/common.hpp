@@ -87,6 +87,17 @@ template <typename T> __device__ __forceinline__ void store8g(T* p, const float 
     for (int i = 0; i < 8; ++i) if (i < nv) st<T>::stv(p + i, v[i]);
 }
 
+// Sum over the lanes of a 16-lane row that share (lane % CLS), CLS = 4 or 8: DPP row rotations, no LDS traffic.  The
+// end-of-kernel folds used __shfl_xor trees (ds_bpermute: a dependent LDS round trip per step) per value: a phase
+// trace of dw_bn_bwd on a one-tile problem showed 26 k of the launch's 47 k cycles in its fold.  Lanes 0..CLS-1 of
+// every ROW then hold a partial (16 / CLS lanes folded); the caller adds the four rows of the wave.
+template <int CLS> __device__ __forceinline__ float row_fold(float v) {
+    static_assert(CLS == 4 || CLS == 8, "lane classes per row");
+    if constexpr (CLS == 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));                           // row_ror:8
+    return v;
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float z, int act) {
     switch (act) {

@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // per-channel constants live in LDS (shared by the four waves) and are re-read at each stash: holding the
     // 9 x 8 floats per lane in registers costs a whole occupancy step
     float* cst = reinterpret_cast<float*>(ldsb + 4 * SLAB);       // [9][64]
+    // W (N x K fp32, <= 16 KB) is staged through the still-unused slab area with coalesced loads: building the MFMA
+    // fragments straight from global memory was 8 * NS * TK dependent scalar loads per lane - a phase trace of a small
+    // launch showed 38 k of its 85 k cycles (64 -> 64 channels) in that prologue
+    float* wl = reinterpret_cast<float*>(ldsb);
+    for (int i = tid; i < p.N * p.K; i += 256) wl[i] = p.w[i];
     if (tid < 64) {
         const int cn = min(tid, p.N - 1), ck = min(tid, p.K - 1);
         cst[0 * 64 + tid] = p.ysc[cn]; cst[1 * 64 + tid] = p.ysh[cn]; cst[2 * 64 + tid] = p.ymu[cn];
@@ -85,8 +90,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int n = 16 * s + 8 * hh + jj, k = 32 * j + r;
-                wb[s][j][jj] = (bf16_t)((n < p.N && k < p.K) ? p.w[(long)n * p.K + k] : 0.f);
+                wb[s][j][jj] = (bf16_t)((n < p.N && k < p.K) ? wl[n * p.K + k] : 0.f);
             }
+    __syncthreads();                                              // the slabs reuse W's staging area
 
     f32x16 acc[TN][TK];
 #pragma unroll
@@ -281,10 +287,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v0 = s0[j], v1 = s1[j];
-#pragma unroll
-            for (int off = VK; off < 64; off <<= 1) { v0 += __shfl_xor(v0, off, 64); v1 += __shfl_xor(v1, off, 64); }
-            if (lane < VK) { atomicAdd(&xr[ck0 + j], v0); atomicAdd(&xr[TK * 32 + ck0 + j], v1); }
+            const float v0 = row_fold<VK>(s0[j]), v1 = row_fold<VK>(s1[j]);      // lanes with equal lane % VK share channels
+            if ((lane & 15) < VK) { atomicAdd(&xr[ck0 + j], v0); atomicAdd(&xr[TK * 32 + ck0 + j], v1); }
         }
         __syncthreads();
         for (int i = tid; i < 2 * TK * 32; i += 256) {

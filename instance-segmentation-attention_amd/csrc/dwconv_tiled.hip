@@ -23,16 +23,6 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Sum over the four lanes of a 16-lane row that share (lane & 3): two DPP row rotations, no LDS traffic.  The end-of-
-// kernel folds used a 4-step __shfl_xor tree (ds_bpermute: an LDS round trip per step, dependent) per value: a phase
-// trace of dw_bn_bwd on a one-tile problem showed 26 k of the launch's 47 k cycles in that fold.  Lanes 0-3 of every
-// row then issue the LDS atomic (16 lanes per wave instead of 4, the same number of instructions).
-__device__ __forceinline__ float row_fold4(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8
-    return v;
-}
-
 constexpr int TH = 8, TW = 32, CB = 32, PS = 36;         // tile rows/cols, channel block, pixel stride (floats)
 constexpr int HALO = (TH + 2) * (TW + 2);
 
@@ -360,7 +350,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
             // lanes with equal (lane & 3) share a channel group: fold the 16 of them, then 4 LDS atomics per wave
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                s1[j] = row_fold4(s1[j]); s2[j] = row_fold4(s2[j]);
+                s1[j] = row_fold<4>(s1[j]); s2[j] = row_fold<4>(s2[j]);
             }
             if ((tid & 15) < 4) {
 #pragma unroll
@@ -440,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = tp < 9 ? acc[tp < 9 ? tp : 0][j] : db[j];
-            v = row_fold4(v);
+            v = row_fold<4>(v);
             if ((tid & 15) < 4) atomicAdd(&red[tp * CB + cg * 8 + j], v);
         }
     }
@@ -900,13 +890,13 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = row_fold4(acc[tp][j]);
+                const float v = row_fold<4>(acc[tp][j]);
                 if (writer) part[(tp * 8 + j) * 64 + slot] = v;
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v0 = row_fold4(s0[j]), v1 = row_fold4(s1[j]);
+            const float v0 = row_fold<4>(s0[j]), v1 = row_fold<4>(s1[j]);
             if (writer) { part[(72 + j) * 64 + slot] = v0; part[(80 + j) * 64 + slot] = v1; }
         }
     }
