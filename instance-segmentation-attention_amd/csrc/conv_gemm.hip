@@ -19,6 +19,7 @@
 //   * bf16 storage: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  f32 storage: v_mfma_f32_32x32x2_f32
 //     (exact fp32 FMA chain) — used for the 1e-3 parity mode.
 #include "common.hpp"
+#include <cstdlib>
 
 int conv3x3_tiled_launch(const isa_tensor* x, const void* w, const float* bias, const isa_tensor* y, int accumulate,
                          hipStream_t s);          // conv3x3_tiled.hip: narrow dense 3x3 convs from an LDS halo tile
@@ -316,6 +317,237 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-tiled variant for the low-resolution 1x1 layers (and their data gradients): M <= 128 K pixels, K = 128..1024.
+// There the problem is a small GEMM, not a stream: with the kernel above every 128-pixel tile re-stages its whole
+// weight slice (M = 4096, N = K = 1024: 64 MB of L2->LDS weight traffic for 17 MB of activations) and the K loop is a
+// chain of K/32 dependent steps on one workgroup per CU - 15-18 us for 6-25 MB problems, ~175 launches per step.
+// Here a workgroup owns a 128 x (64 | 128) output tile, BOTH operands go through double-buffered LDS tiles of 64
+// contraction steps (rows padded by 16 B: conflict-free ds_read_b128 fragments, the same K order in A and B), the
+// next tile's global loads are in registers while the MFMAs of the current one run, one barrier per step.  The lazy
+// prologue is applied once per element when the A tile is written to LDS.  Epilogue as above (bias, statistics,
+// transpose through LDS, 16-byte row stores, optional accumulate).
+template <int WN, int PRO>
+__global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
+    constexpr int BM = 128, BK = 64, BN = 64 * WN, LDT = BK + 8;
+    constexpr bool HAS_PRO = PRO != 0;
+    constexpr int ACT = PRO == 1 ? ISA_ACT_RELU6 : ACT_RT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                  // [2][BM][LDT]
+    bf16_t* sB = sA + 2 * BM * LDT;                                // [2][BN][LDT]
+    float* pro_tab = reinterpret_cast<float*>(sB + 2 * BN * LDT);  // [2][K]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN, K = p.kp;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* wg = reinterpret_cast<const bf16_t*>(p.w);
+    if constexpr (HAS_PRO) {
+        for (int k = tid; k < K; k += 256) {
+            pro_tab[k] = p.pro.scale ? p.pro.scale[k] : 1.f;
+            pro_tab[K + k] = p.pro.shift ? p.pro.shift[k] : 0.f;
+        }
+    }
+    // staging: thread -> rows srow + 32 i, 8 contraction elements at sseg
+    const int srow = tid >> 3, sseg = (tid & 7) * 8;
+    long aoff[4];
+    const float* bsrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long m = m0 + srow + 32 * i;
+        if (m > p.M - 1) m = p.M - 1;                              // rows >= M read the last valid row; the epilogue masks them
+        aoff[i] = m * p.ldx + sseg;
+        bsrow[i] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale + (m / ((long)p.mh * p.mw)) * p.cin + sseg : nullptr;
+    }
+    // two register sets: the loads of K tile kt + 2 are issued while tile kt is multiplied and tile kt + 1 is written
+    // to LDS - with one workgroup per CU on these small problems nothing else covers the memory latency
+    struct Regs { bf16x8 a[4], b[BN / 32]; };
+    long boff[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+        int n = n0 + srow + 32 * i;
+        if (n > p.N - 1) n = p.N - 1;                              // rows >= N read the last valid row; zeroed when stashed
+        boff[i] = (long)n * K + sseg;
+    }
+    auto fetch = [&](Regs& R, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.a[i] = *reinterpret_cast<const bf16x8*>(xin + aoff[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) R.b[i] = *reinterpret_cast<const bf16x8*>(wg + boff[i] + kt * BK);
+        asm volatile("" ::: "memory");                              // keep the prefetch here (LLVM sinks loads to their use)
+    };
+    auto stash = [&](const Regs& R, int buf, int kt) {
+        const bf16x8 (&ra)[4] = R.a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 o = ra[i];
+            if constexpr (HAS_PRO) {
+                const int k = kt * BK + sseg;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(pro_tab + k), s1 = *reinterpret_cast<const f32x4*>(pro_tab + k + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(pro_tab + K + k), h1 = *reinterpret_cast<const f32x4*>(pro_tab + K + k + 4);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = act_t<ACT>(fmaf((float)ra[i][j], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? h0[j & 3] : h1[j & 3]), p.pro.act);
+                if (bsrow[i]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= bsrow[i][kt * BK + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+            }
+            *reinterpret_cast<bf16x8*>(sA + (buf * BM + srow + 32 * i) * LDT + sseg) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+            *reinterpret_cast<bf16x8*>(sB + (buf * BN + srow + 32 * i) * LDT + sseg) = (n0 + srow + 32 * i < p.N) ? R.b[i] : bf16x8{0};
+    };
+
+    f32x16 acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x16{0};
+    const int KT = K / BK;                                         // >= 2 (K >= 128)
+    Regs R0, R1;
+    fetch(R0, 0);
+    fetch(R1, 1);
+    __syncthreads();                                               // pro_tab
+    stash(R0, 0, 0);
+    __syncthreads();
+    auto step = [&](int kt, Regs& Rnext, Regs& Rfree) {            // Rnext holds tile kt + 1; Rfree (tile kt, already in LDS) takes kt + 2
+        const int buf = kt & 1;
+        if (kt + 2 < KT) fetch(Rfree, kt + 2);
+        const bf16_t* tA = sA + (buf * BM + wm * 64 + r) * LDT + 8 * hh;
+        const bf16_t* tB = sB + (buf * BN + wn * 32 * WN + r) * LDT + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 a[2], b[WN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tA + i * 32 * LDT + s * 16);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tB + j * 32 * LDT + s * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) stash(Rnext, buf ^ 1, kt + 1);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+        step(kt, R1, R0);
+        if (kt + 1 < KT) step(kt + 1, R0, R1);
+    }
+
+    // ---------------- epilogue (the tile buffers are free now): lane r <-> output channel -----------------------
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+    float st_sum[WN], st_sq[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { st_sum[j] = 0.f; st_sq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long mbase = m0 + wm * 64 + i * 32;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int nb = n0 + wn * 32 * WN + j * 32;
+            const int n = nb + r;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const float v = acc[i][j][e] + bv;
+                if (mbase + row < p.M) { s += v; s2 += v * v; }
+                stage[row * 33 + r] = v;
+            }
+            if (p.stats) {
+                s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                st_sum[j] += s; st_sq[j] += s2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int row = lane >> 1, cseg = (lane & 1) * 16;
+            const long mr = mbase + row;
+            const int nseg = nb + cseg;
+            if (mr < p.M && nseg < p.N) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + mr * p.ldy + nseg;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = stage[row * 33 + cseg + q];
+                const bool full = (nseg + 16 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+                if (full) {
+                    float lo[8], hi[8];
+                    if (p.accumulate) {
+                        load8<bf16_t>(dst, lo); load8<bf16_t>(dst + 8, hi);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { lo[q] += v[q]; hi[q] += v[8 + q]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { lo[q] = v[q]; hi[q] = v[8 + q]; }
+                    }
+                    store8<bf16_t>(dst, lo); store8<bf16_t>(dst + 8, hi);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (nseg + q < p.N) {
+                            float o = v[q];
+                            if (p.accumulate) o += st<bf16_t>::ld(dst + q);
+                            st<bf16_t>::stv(dst + q, o);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.stats) {
+        __shared__ float sred[2 * 128];
+        if (tid < 2 * BN) sred[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int c = wn * 32 * WN + j * 32 + r;
+            if (hh == 0) { atomicAdd(&sred[c], st_sum[j]); atomicAdd(&sred[BN + c], st_sq[j]); }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, n = n0 + (tid - which * BN);
+            if (n < p.N) {
+                float* rep = p.stats + (blockIdx.x & (ISA_STAT_R - 1)) * 2 * p.N;
+                atomicAdd(rep + which * p.N + n, sred[tid]);
+            }
+        }
+    }
+}
+
+template <int WN>
+int launch_tiled(const GemmParams& p, bool has_pro, hipStream_t s) {
+    constexpr int BN = 64 * WN, LDT = 72;
+    const size_t tiles = 2 * (size_t)(128 + BN) * LDT * 2;
+    const size_t lds = tiles + (has_pro ? 2 * (size_t)p.kp * 4 : 0);
+    const long grid = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
+    const void* fn = has_pro && p.pro.act == ISA_ACT_RELU6 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 1>)
+                   : has_pro ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 2>)
+                             : reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 0>);
+    if (lds > 64 * 1024) {
+        static bool configured[3] = {false, false, false};
+        const int idx = has_pro && p.pro.act == ISA_ACT_RELU6 ? 1 : (has_pro ? 2 : 0);
+        if (!configured[idx]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ISA_ELAUNCH;
+            configured[idx] = true;
+        }
+    }
+    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 1>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else if (has_pro) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 2>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 0>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    return launch_status();
+}
+
 template <typename T, int NT, int IN_MODE, int OUT_MODE>
 int launch2(const GemmParams& p, bool has_pro, dim3 grid, size_t lds, hipStream_t s) {
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1>), grid, dim3(256), lds, s, p);
@@ -341,6 +573,19 @@ int launch1(const GemmParams& p, bool has_pro, int in_mode, int out_mode, dim3 g
 
 template <typename T>
 int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        // low-resolution 1x1 layers: small GEMMs, both operands through LDS (conv_gemm_tiled_kernel)
+        static const long tiled_max_m = getenv("ISA_GEMM_TILED_MAX_M") ? atol(getenv("ISA_GEMM_TILED_MAX_M")) : 65536;
+        if (in_mode == ISA_IN_1X1 && out_mode == ISA_OUT_PLAIN && p.cin == p.kp && p.kp >= 128 && p.kp % 64 == 0 && p.kp <= 2048 &&
+            p.N >= 64 && p.N % 16 == 0 && p.M <= tiled_max_m)
+        {
+            static const long wide_min_wgs = getenv("ISA_GEMM_TILED_WIDE_MIN") ? atol(getenv("ISA_GEMM_TILED_WIDE_MIN")) : 512;
+            // 128-wide column tiles only when they still give >= 2 workgroups per CU: the second resident workgroup is
+            // what keeps the MFMA pipe busy while the first one writes its next tile to LDS and waits at the barrier
+            return (p.N >= 128 && ((p.M + 127) / 128) * ((p.N + 127) / 128) >= wide_min_wgs) ? launch_tiled<2>(p, has_pro, s)
+                                                                                               : launch_tiled<1>(p, has_pro, s);
+        }
+    }
     int nt = p.N <= 32 ? 1 : (p.N <= 64 ? 2 : 4);
     // low-resolution levels: few 128-pixel tiles but hundreds of output channels.  Narrower column tiles put more
     // workgroups on the chip (the re-read A operand is L2-resident at these sizes): 4096 px x 512 ch ran as 128

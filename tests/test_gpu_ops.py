@@ -68,7 +68,10 @@ def rand(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,hw,batch", [(32, 32, 16, 2), (21, 32, 8, 1), (64, 246, 8, 2),
                                                (512, 1024, 4, 2), (256, 120, 8, 1), (24, 12, 8, 2),
-                                               (32, 2, 16, 2)])
+                                               (32, 2, 16, 2),
+                                               # the LDS-tiled small-GEMM path (bf16, K >= 128, K % 64 == 0, N % 16 == 0):
+                                               # ragged M, column tails of both tile widths, several K steps
+                                               (128, 80, 12, 3), (192, 64, 9, 2), (1024, 512, 16, 1), (128, 144, 5, 1)])
 def test_conv1x1(dtype, cin, cout, hw, batch):
     L, Act, Engine, ParamStore, Pro = _gpu()
     w = rand(cout, cin, 1, 1, seed=1, scale=cin ** -0.5)
@@ -91,9 +94,11 @@ def test_conv1x1(dtype, cin, cout, hw, batch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv1x1_lazy_prologue(dtype):
+@pytest.mark.parametrize("cin,cout,hw,batch", [(48, 24, 8, 2), (128, 96, 10, 3), (256, 64, 7, 2)])
+def test_conv1x1_lazy_prologue(dtype, cin, cout, hw, batch):
+    # the last two shapes take the LDS-tiled path in bf16; images of 100 / 49 pixels straddle its 128-row tiles, so the
+    # per-image channel multiplier changes inside a tile
     L, Act, Engine, ParamStore, Pro = _gpu()
-    cin, cout, hw, batch = 48, 24, 8, 2
     w = rand(cout, cin, 1, 1, seed=1, scale=cin ** -0.5)
     x = rand(batch, cin, hw, hw, seed=3, scale=3.0)
     sc, sh = rand(cin, seed=4).abs() + 0.5, rand(cin, seed=5)
