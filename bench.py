@@ -175,6 +175,13 @@ def main():
         # ---- roofline: one extra instrumented step, events on the launch stream -----------------
         E = model.engine
         E.profile = True
+        # one stream for this step: with the decoder iterations overlapped on two streams an event pair around a launch
+        # also times whatever the other stream runs meanwhile (26.3 us per conv_gemm launch against 20.3 us in the rocprofv3
+        # trace of the same command)
+        head = getattr(model, "head", None)
+        saved_streams = getattr(head, "streams", None)
+        if saved_streams is not None:
+            head.streams = 1
         if workload == "train_step":                              # per-launch events need the eager launch loop
             # forward + backward only: this block runs on rank 0 alone, so it must stay collective-free (the update's
             # all-reduce would wait forever for the other ranks)
@@ -185,6 +192,8 @@ def main():
             step()
         prof = E.profile_summary()
         E.profile = False
+        if saved_streams is not None:
+            head.streams = saved_streams
         fam = {k: v for k, v in prof.items() if v[2] > 0}
         if fam:
             dom = max(fam.items(), key=lambda kv: kv[1][1])

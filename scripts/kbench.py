@@ -7,9 +7,25 @@ import isa_amd  # noqa
 from isa_amd import lib as L
 from isa_amd.engine import Act, Engine, ParamStore, Pro
 
+_FLUSH = None
+
 def timeit(fn, reps=20):
+    """KBENCH_FLUSH=1: a 512 MB fill runs between repetitions and every repetition has its own event pair, so the
+    operands come from HBM and not from the 256 MB Infinity Cache a back-to-back loop leaves them in."""
+    global _FLUSH
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    if os.environ.get("KBENCH_FLUSH") == "1":
+        if _FLUSH is None:
+            _FLUSH = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+        tot = 0.0
+        for i in range(reps):
+            _FLUSH.fill_(i & 1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); fn(); e.record()
+            torch.cuda.synchronize()
+            tot += s.elapsed_time(e)
+        return tot / reps * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps): fn()
