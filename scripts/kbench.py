@@ -51,9 +51,7 @@ def main(dtype=torch.bfloat16, which=None):
                             "bn.running_var": torch.ones(c)})
         eng = Engine(ps, dtype)
         eng.begin(True, False)
-        x, y, dy = rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype)
         sc, sh = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda")
-        xl = x.with_pro(Pro(sc, sh, L.ACT_RELU6))
         nbytes = B * hw * hw * c * esz
         st = torch.zeros(16 * c, device="cuda")
         mean, inv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
@@ -68,26 +66,42 @@ def main(dtype=torch.bfloat16, which=None):
                          dgam.data_ptr(), dbet.data_ptr(), float(B * hw * hw), L.ACT_RELU6)
         xbn = L.IsaBnBwd(sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), None, xred.data_ptr(), None, None,
                          float(B * hw * hw), L.ACT_RELU6)
-        dx = rnd(B, hw, hw, c, dtype)
         wlin = torch.randn(c, c, device="cuda") * c ** -0.5
         dwl = torch.zeros(c, c, device="cuda")
-        tests = {
-            "conv1x1": (lambda: lib.isa_conv_gemm(x.d(), None, eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
-            "conv1x1+pro": (lambda: lib.isa_conv_gemm(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
-            "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
-            "wgrad1x1_nopro": (lambda: lib.isa_conv_wgrad(x.d(), None, dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
-            "dw+pro": (lambda: lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(regd["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), 2),
-            "dw_dgrad": (lambda: lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(regd["dgrad"]), y.d(), 0, L.stream_ptr()), 2),
-            "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
-            "dw_bn_bwd": (lambda: lib.isa_dwconv3x3_bn_backward(dy.d(), y.d(), C.byref(ybn), xl.d(), xl.p(), C.byref(xbn), eng.packer.ptr(regd["dgrad"]), ps.gptr("wd"), c, dx.d(), 0, None, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 4),
-            "pw_bn_bwd": ((lambda: lib.isa_conv1x1_bn_backward(dy.d(), y.d(), C.byref(ybn), xl.d(), xl.p(), C.byref(xbn), L.ptr(wlin), L.ptr(dwl), dx.d(), 0, None, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr())) if c <= 64 else None, 4),
-            "bn_bwd_reduce": (lambda: lib.isa_bn_bwd_reduce(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, L.ptr(red), L.stream_ptr()), 2),
-            "bn_bwd_apply": (lambda: lib.isa_bn_bwd_apply(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, ps.ptr("bn.weight"), L.ptr(red), float(B * hw * hw), 1, y.d(), None, None, L.stream_ptr()), 3),
-            "materialize+res": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), dy.d(), None, None, y.d(), L.stream_ptr()), 3),
-        }
+        # KBENCH_ROTATE=n: n independent operand sets are cycled, so with n x (4 tensors) > 256 MB every repetition finds its
+        # inputs in HBM like a launch inside a training step does (back-to-back runs on one set are Infinity-Cache warm)
+        nsets = int(os.environ.get("KBENCH_ROTATE", "1"))
+        def make_tests():
+            x, y, dy, dx = rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype), rnd(B, hw, hw, c, dtype)
+            xl = x.with_pro(Pro(sc, sh, L.ACT_RELU6))
+            tests = {
+                "conv1x1": (lambda: lib.isa_conv_gemm(x.d(), None, eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
+                "conv1x1+pro": (lambda: lib.isa_conv_gemm(xl.d(), xl.p(), eng.packer.ptr(reg["fwd"]), reg["kp"], None, y.d(), 0, 0, L.ptr(st), 0, L.stream_ptr()), 2),
+                "wgrad1x1": (lambda: lib.isa_conv_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
+                "wgrad1x1_nopro": (lambda: lib.isa_conv_wgrad(x.d(), None, dy.d(), ps.gptr("w"), None, 0, 0, None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
+                "dw+pro": (lambda: lib.isa_dwconv3x3(xl.d(), xl.p(), eng.packer.ptr(regd["fwd"]), None, y.d(), L.ptr(st), L.stream_ptr()), 2),
+                "dw_dgrad": (lambda: lib.isa_dwconv3x3_dgrad(dy.d(), eng.packer.ptr(regd["dgrad"]), y.d(), 0, L.stream_ptr()), 2),
+                "dw_wgrad": (lambda: lib.isa_dwconv3x3_wgrad(xl.d(), xl.p(), dy.d(), ps.gptr("wd"), None, c, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 2),
+                "dw_bn_bwd": (lambda: lib.isa_dwconv3x3_bn_backward(dy.d(), y.d(), C.byref(ybn), xl.d(), xl.p(), C.byref(xbn), eng.packer.ptr(regd["dgrad"]), ps.gptr("wd"), c, dx.d(), 0, None, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr()), 4),
+                "pw_bn_bwd": ((lambda: lib.isa_conv1x1_bn_backward(dy.d(), y.d(), C.byref(ybn), xl.d(), xl.p(), C.byref(xbn), L.ptr(wlin), L.ptr(dwl), dx.d(), 0, None, L.ptr(eng.ws), eng.ws.numel(), None, L.stream_ptr())) if c <= 64 else None, 4),
+                "bn_bwd_reduce": (lambda: lib.isa_bn_bwd_reduce(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, L.ptr(red), L.stream_ptr()), 2),
+                "bn_bwd_apply": (lambda: lib.isa_bn_bwd_apply(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, ps.ptr("bn.weight"), L.ptr(red), float(B * hw * hw), 1, y.d(), None, None, L.stream_ptr()), 3),
+                "materialize+res": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), dy.d(), None, None, y.d(), L.stream_ptr()), 3),
+            }
+            return tests
+        sets = [make_tests() for _ in range(nsets)]
+        tests = sets[0]
+        def rotating(name):
+            fns = [t[name][0] for t in sets]
+            if fns[0] is None: return None
+            state = [0]
+            def call():
+                state[0] = (state[0] + 1) % len(fns)
+                return fns[state[0]]()
+            return call
         for name, (fn, ntens) in tests.items():
             if fn is None or (which and which not in name): continue
-            us = timeit(fn)
+            us = timeit(rotating(name))
             rows.append((name, hw, c, us, ntens * nbytes / us / 1e3))
     print("%-18s %5s %5s %10s %10s" % ("kernel", "hw", "c", "us", "GB/s(alg)"))
     for r in sorted(rows):
