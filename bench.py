@@ -70,10 +70,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # ISA_DIST_REHEARSAL=1: all ranks share the visible GPU(s) and exchange over gloo - the only way to execute the
+    # world > 1 branch (graph for forward+backward, eager exchange + update) on a one-GPU box; never a measurement
+    rehearsal = os.environ.get("ISA_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     workload = args.workload

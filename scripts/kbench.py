@@ -87,6 +87,7 @@ def main(dtype=torch.bfloat16, which=None):
                 "bn_bwd_reduce": (lambda: lib.isa_bn_bwd_reduce(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, L.ptr(red), L.stream_ptr()), 2),
                 "bn_bwd_apply": (lambda: lib.isa_bn_bwd_apply(dy.d(), x.d(), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(inv), L.ACT_RELU6, None, ps.ptr("bn.weight"), L.ptr(red), float(B * hw * hw), 1, y.d(), None, None, L.stream_ptr()), 3),
                 "materialize+res": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), dy.d(), None, None, y.d(), L.stream_ptr()), 3),
+                "materialize": (lambda: lib.isa_affine_act_res(xl.d(), xl.p(), None, None, None, y.d(), L.stream_ptr()), 2),
             }
             return tests
         sets = [make_tests() for _ in range(nsets)]
