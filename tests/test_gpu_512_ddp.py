@@ -105,14 +105,19 @@ def test_world2_branch_of_the_graphed_step():
             return m.store.flat.clone(), m.store.grad.clone()
 
         p_e, g_e = run(tr.train_step)
+        p_e2, g_e2 = run(tr.train_step)                  # the eager step against itself: float atomics reorder sums and a
+        # ReLU6 / clamp threshold flip moves every upstream gradient (see test_gpu_train._check_gradients), so two runs
+        # of the SAME path already differ; the graph path is held to a few times that, not to a fixed epsilon
+        noise_cos = 1.0 - float(torch.nn.functional.cosine_similarity(g_e2.double(), g_e.double(), dim=0))
+        noise_p = float((p_e2 - p_e).abs().max())
         run(tr.train_step_graphed)                       # first sight: eager
         p_c, g_c = run(tr.train_step_graphed)            # capture (forward + backward), update outside the graph
         p_r, g_r = run(tr.train_step_graphed)            # replay
         assert any(s.get("state") == "ready" for s in tr._graphs.values()), "graph was never captured"
         for name, p, g in (("capture", p_c, g_c), ("replay", p_r, g_r)):
             cos = float(torch.nn.functional.cosine_similarity(g.double(), g_e.double(), dim=0))
-            assert cos > 0.9995, (name, cos)
-            assert float((p - p_e).abs().max()) < 2e-2, name
+            assert 1.0 - cos <= max(5e-4, 5.0 * noise_cos), (name, cos, noise_cos)
+            assert float((p - p_e).abs().max()) <= max(2e-2, 5.0 * noise_p), (name, noise_p)
         # the averaging scale reached the optimizer: a world-1 trainer from the same state takes a different step
         tr1 = Trainer(m, world_size=1)
         m.store.flat.copy_(snap["flat"]); m.store.int_buffers.update(snap["ib"]); m.head.baseline = None
