@@ -56,6 +56,13 @@ typedef struct isa_pro {       /* lazy-input prologue; all pointers may be NULL 
     int32_t      act;          /* ISA_ACT_* applied after the affine, before bscale */
 } isa_pro;
 
+typedef struct isa_conv_ep {   /* output epilogue of isa_conv_gemm_ep: y = act(scale[n]*(conv+bias) + shift[n]) + res */
+    const float* scale;        /* [N] eval-mode BatchNorm scale  gamma / sqrt(running_var + eps)          */
+    const float* shift;        /* [N]                     shift  beta - running_mean * scale               */
+    int32_t      act;          /* ISA_ACT_* applied after the affine                                        */
+    const isa_tensor* res;     /* optional residual branch, same shape and dtype as y (may be NULL)         */
+} isa_conv_ep;
+
 typedef struct isa_slab_arena isa_slab_arena;   /* opaque: deferred weight-gradient folds, see below */
 
 typedef struct isa_pack_entry { /* one parameter tensor to repack (see isa_pack_weights) */
@@ -94,6 +101,13 @@ int isa_pack_weights(const isa_pack_entry* table_dev, int32_t n_entries, const i
 int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
                   const float* bias, const isa_tensor* y, int32_t in_mode, int32_t out_mode,
                   float* stats, int32_t accumulate, void* stream);
+
+/* The same convolution with an output epilogue: eval-mode BatchNorm2d (a constant per-channel affine), the activation and
+ * the block's residual add are applied before the store, so `model.eval()` needs neither a lazy prologue in the consumer
+ * nor the materialising pass of a block output (reference: nn.Sequential(conv, BatchNorm2d, ReLU6) in eval mode and
+ * `x + self.conv(x)`, MobileNetDenseASPP.py:68-123).  No statistics, no accumulate, plain output layout.           */
+int isa_conv_gemm_ep(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
+                     const float* bias, const isa_tensor* y, int32_t in_mode, const isa_conv_ep* ep, void* stream);
 
 /* Weight gradient of the same family, accumulated straight into the reference's state_dict layout:
  * dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)

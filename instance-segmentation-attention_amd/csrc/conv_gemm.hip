@@ -36,6 +36,8 @@ struct GemmParams {
     void* y; int oh, ow, N, ldy, cout;          // cout: channels per shuffle quadrant
     float* stats; int accumulate;
     int ntiles;
+    // optional output epilogue (isa_conv_gemm_ep): y = act(ep_scale[n] * (conv + bias) + ep_shift[n]) + res
+    const float *ep_scale, *ep_shift; int ep_act; const void* res; int ldres;
 };
 
 template <typename T> struct Frag;      // 16 contiguous channels of one pixel
@@ -80,7 +82,9 @@ __device__ __forceinline__ void frag_set(Frag<T>& f, int j, float x) {
     f.v[j / V][j % V] = (T)x;
 }
 
-template <typename T, int NT, int IN_MODE, int OUT_MODE, int PRO>
+// EP: the output epilogue of isa_conv_gemm_ep is its own instantiation - folded into the common one it cost the training
+// launches 4 % (registers and epilogue code on every launch).
+template <typename T, int NT, int IN_MODE, int OUT_MODE, int PRO, bool EP = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N_BLK = 32 * NT;
@@ -236,11 +240,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
             const int n = n0 + t * 32 + r;
             // bias is per output channel; in pixel-shuffle mode GEMM column n = quadrant*cout + co
             const float bv = (p.bias && n < p.N) ? p.bias[OUT_MODE == ISA_OUT_SHUFFLE2 ? n % p.cout : n] : 0.f;
+            constexpr bool has_ep = EP;
+            const float es = (has_ep && n < p.N) ? p.ep_scale[n] : 1.f, eh = (has_ep && n < p.N) ? p.ep_shift[n] : 0.f;
             float s = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 float v = acc[t][i] + bv;
+                if (has_ep) v = act_apply(fmaf(v, es, eh), p.ep_act);
                 if (mbase + row < p.M) { s += v; s2 += v * v; }
                 stage[row * 33 + r] = v;
             }
@@ -269,6 +276,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                 float v[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = stage[row * 33 + cseg + j];
+                if (EP && p.res) {                                 // residual branch (16 channels of this row)
+                    const T* rs = reinterpret_cast<const T*>(p.res) + mr * p.ldres + nseg;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (nseg + j < p.N) v[j] += st<T>::ld(rs + j);
+                }
                 const bool full = (nseg + 16 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
                 if (full) {
                     float lo[8], hi[8];
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 // next tile's global loads are in registers while the MFMAs of the current one run, one barrier per step.  The lazy
 // prologue is applied once per element when the A tile is written to LDS.  Epilogue as above (bias, statistics,
 // transpose through LDS, 16-byte row stores, optional accumulate).
-template <int WN, int PRO>
+template <int WN, int PRO, bool EP = false>
 __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
     constexpr int BM = 128, BK = 64, BN = 64 * WN, LDT = BK + 8;
     constexpr bool HAS_PRO = PRO != 0;
@@ -456,11 +469,14 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
             const int nb = n0 + wn * 32 * WN + j * 32;
             const int n = nb + r;
             const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            constexpr bool has_ep = EP;
+            const float es = (has_ep && n < p.N) ? p.ep_scale[n] : 1.f, eh = (has_ep && n < p.N) ? p.ep_shift[n] : 0.f;
             float s = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const float v = acc[i][j][e] + bv;
+                float v = acc[i][j][e] + bv;
+                if (has_ep) v = act_apply(fmaf(v, es, eh), p.ep_act);
                 if (mbase + row < p.M) { s += v; s2 += v * v; }
                 stage[row * 33 + r] = v;
             }
@@ -478,6 +494,12 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
                 float v[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] = stage[row * 33 + cseg + q];
+                if (EP && p.res) {
+                    const bf16_t* rs = reinterpret_cast<const bf16_t*>(p.res) + mr * p.ldres + nseg;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (nseg + q < p.N) v[q] += st<bf16_t>::ld(rs + q);
+                }
                 const bool full = (nseg + 16 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
                 if (full) {
                     float lo[8], hi[8];
@@ -525,31 +547,43 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
     }
 }
 
-template <int WN>
-int launch_tiled(const GemmParams& p, bool has_pro, hipStream_t s) {
+template <int WN, bool EP>
+int launch_tiled_ep(const GemmParams& p, bool has_pro, hipStream_t s) {
     constexpr int BN = 64 * WN, LDT = 72;
     const size_t tiles = 2 * (size_t)(128 + BN) * LDT * 2;
     const size_t lds = tiles + (has_pro ? 2 * (size_t)p.kp * 4 : 0);
     const long grid = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
-    const void* fn = has_pro && p.pro.act == ISA_ACT_RELU6 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 1>)
-                   : has_pro ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 2>)
-                             : reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 0>);
+    const int idx = has_pro && p.pro.act == ISA_ACT_RELU6 ? 1 : (has_pro ? 2 : 0);
+    const void* fn = idx == 1 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 1, EP>)
+                   : idx == 2 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 2, EP>)
+                              : reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 0, EP>);
     if (lds > 64 * 1024) {
         static bool configured[3] = {false, false, false};
-        const int idx = has_pro && p.pro.act == ISA_ACT_RELU6 ? 1 : (has_pro ? 2 : 0);
         if (!configured[idx]) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ISA_ELAUNCH;
             configured[idx] = true;
         }
     }
-    if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 1>), dim3((unsigned)grid), dim3(256), lds, s, p);
-    else if (has_pro) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 2>), dim3((unsigned)grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 0>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    if (idx == 1) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 1, EP>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else if (idx == 2) hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 2, EP>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_gemm_tiled_kernel<WN, 0, EP>), dim3((unsigned)grid), dim3(256), lds, s, p);
     return launch_status();
+}
+template <int WN>
+int launch_tiled(const GemmParams& p, bool has_pro, hipStream_t s) {
+    return p.ep_scale ? launch_tiled_ep<WN, true>(p, has_pro, s) : launch_tiled_ep<WN, false>(p, has_pro, s);
 }
 
 template <typename T, int NT, int IN_MODE, int OUT_MODE>
 int launch2(const GemmParams& p, bool has_pro, dim3 grid, size_t lds, hipStream_t s) {
+    if constexpr (OUT_MODE == ISA_OUT_PLAIN && IN_MODE != ISA_IN_GATHER2) {
+        if (p.ep_scale) {
+            if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1, true>), grid, dim3(256), lds, s, p);
+            else if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 2, true>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 0, true>), grid, dim3(256), lds, s, p);
+            return launch_status();
+        }
+    }
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1>), grid, dim3(256), lds, s, p);
     else if (has_pro && p.pro.act == ISA_ACT_LEAKY && IN_MODE == ISA_IN_3X3) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 3>), grid, dim3(256), lds, s, p);
     else if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 2>), grid, dim3(256), lds, s, p);
@@ -616,9 +650,9 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
 
 }  // namespace
 
-extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
-                             const float* bias, const isa_tensor* y, int32_t in_mode,
-                             int32_t out_mode, float* stats, int32_t accumulate, void* stream) {
+static int conv_gemm_impl(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
+                          const float* bias, const isa_tensor* y, int32_t in_mode,
+                          int32_t out_mode, float* stats, int32_t accumulate, const isa_conv_ep* ep, void* stream) {
     if (!tensor_ok(x, 8) || !tensor_ok(y, 1) || !w || x->dtype != y->dtype) return ISA_EINVAL;
     if (kp <= 0 || kp % 32 || kp < x->c) return ISA_EINVAL;
     if (y->ld % 8) return ISA_EALIGN;
@@ -629,6 +663,15 @@ extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void
     p.bias = bias;
     p.y = y->data; p.oh = y->h; p.ow = y->w; p.ldy = y->ld;
     p.stats = stats; p.accumulate = accumulate;
+    if (ep) {
+        if (!ep->scale || !ep->shift || stats || accumulate || out_mode != ISA_OUT_PLAIN || in_mode == ISA_IN_GATHER2) return ISA_EINVAL;
+        p.ep_scale = ep->scale; p.ep_shift = ep->shift; p.ep_act = ep->act;
+        if (ep->res) {
+            const isa_tensor* r = ep->res;
+            if (!tensor_ok(r, 1) || r->dtype != y->dtype || r->n != y->n || r->h != y->h || r->w != y->w || r->c != y->c) return ISA_EINVAL;
+            p.res = r->data; p.ldres = r->ld;
+        }
+    }
     p.taps = in_mode == ISA_IN_3X3 ? 9 : (in_mode == ISA_IN_GATHER2 ? 4 : 1);
     p.total_groups = p.taps * (kp / 32);
     if (in_mode == ISA_IN_GATHER2) {
@@ -647,9 +690,21 @@ extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void
     p.M = (long)x->n * p.mh * p.mw;
     if (p.M >= (1L << 31)) return ISA_EINVAL;
     const bool has_pro = !pro_trivial(p.pro);
-    if (in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && !has_pro && !stats && kp == 32 &&
+    if (!ep && in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && !has_pro && !stats && kp == 32 &&
         y->c <= 32)
         return conv3x3_tiled_launch(x, w, bias, y, accumulate, as_stream(stream));
     if (x->dtype == ISA_BF16) return launch0<bf16_t>(p, has_pro, in_mode, out_mode, as_stream(stream));
     return launch0<float>(p, has_pro, in_mode, out_mode, as_stream(stream));
+}
+
+extern "C" int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
+                             const float* bias, const isa_tensor* y, int32_t in_mode,
+                             int32_t out_mode, float* stats, int32_t accumulate, void* stream) {
+    return conv_gemm_impl(x, pro, w, kp, bias, y, in_mode, out_mode, stats, accumulate, nullptr, stream);
+}
+
+extern "C" int isa_conv_gemm_ep(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
+                                const float* bias, const isa_tensor* y, int32_t in_mode, const isa_conv_ep* ep, void* stream) {
+    if (!ep) return ISA_EINVAL;
+    return conv_gemm_impl(x, pro, w, kp, bias, y, in_mode, ISA_OUT_PLAIN, nullptr, 0, ep, stream);
 }

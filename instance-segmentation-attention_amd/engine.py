@@ -482,6 +482,9 @@ class Engine:
         self._dw_out: Dict[tuple, dict] = {}
         # the same for bias-free 1x1 convs with <= 64 channels either side (isa_conv1x1_bn_backward, bf16 only)
         self.fuse_pw_bn = os.environ.get("ISA_FUSE_PW_BN", "1") != "0"
+        # eval mode: BatchNorm (a constant affine), activation and residual ride in the conv's output epilogue
+        # (isa_conv_gemm_ep) instead of a lazy prologue in the consumer plus a materialising pass per block
+        self.fuse_eval = os.environ.get("ISA_FUSE_EVAL", "1") != "0"
         self._pw_out: Dict[tuple, dict] = {}
         self._pw_in: Dict[tuple, dict] = {}      # conv input -> the same records: residual gradients ride along
         # eval-mode BN constants per layer: persistent buffers (a captured inference graph reads them), recomputed in
@@ -651,6 +654,40 @@ class Engine:
         f = self.packer.add(wname, "fwd", 0, n, k, taps, kp, n, kmap)
         b = self.packer.add(wname, "dgrad", 1, n, k, taps, rup(n, 32), kphys, kmap)
         return dict(fwd=f, dgrad=b, kp=kp, kp_d=rup(n, 32), n=n, kphys=kphys)
+
+    def eval_fusable(self):
+        """True when a forward pass may fold BatchNorm / activation / residual into conv epilogues: eval statistics, no tape."""
+        return self.fuse_eval and not self.bn_train and not self.record
+
+    def eval_bn(self, pre, c):
+        """(scale, shift, mean, invstd) of an eval-mode BatchNorm: constants of the running statistics, computed once per
+        weight version and cached (captured graphs keep reading the same buffers)."""
+        cached = self.eval_bn_cache.get(pre)
+        if cached is None:
+            P = self.params
+            cached = tuple(torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
+            self.eval_bn_cache[pre] = cached
+            L.check(self.lib.isa_bn_finalize(None, 1.0, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                             P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
+                                             self.BN_MOMENTUM, self.BN_EPS, L.ptr(cached[0]), L.ptr(cached[1]),
+                                             L.ptr(cached[2]), L.ptr(cached[3]), c, self.st()), "isa_bn_finalize")
+        return cached
+
+    def conv_bn_eval(self, x: Act, wname, out: Act, bn_pre, act, res: Optional[Act] = None, taps=1):
+        """Eval mode only: out = act(BN(conv(pro(x)))) (+ res) in ONE launch (isa_conv_gemm_ep); `out` is a plain tensor."""
+        assert self.eval_fusable()
+        reg = self.reg_conv(wname, taps, None, False)
+        if self.packer.table is None:
+            self.packer.pack()
+        scale, shift, _, _ = self.eval_bn(bn_pre, out.c)
+        if self.profile:
+            esz = x.buf.element_size()
+            self.next_bytes = (x.n * x.h * x.w * x.c + (1 + (res is not None)) * out.n * out.h * out.w * out.c) * esz
+        ep = L.IsaConvEp(L.addr(scale), L.addr(shift), act, C.addressof(res._c) if res is not None else None)
+        self._keep_ep = (ep, res)                                  # ctypes argument lifetime: until the call returns
+        L.check(self.lib.isa_conv_gemm_ep(x.d(), x.p(), self.packer.ptr(reg["fwd"]), reg["kp"], None, out.d(),
+                                          L.IN_3X3 if taps == 9 else L.IN_1X1, C.byref(ep), self.st()), "isa_conv_gemm_ep")
+        return out
 
     def conv(self, x: Act, wname, out: Act, *, taps=1, bias=None, stats=False, kmap=None,
              transposed=False, record_bwd=True):

@@ -30,6 +30,10 @@ class IsaPro(C.Structure):
                 ("act", C.c_int32)]
 
 
+class IsaConvEp(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int32), ("res", C.c_void_p)]
+
+
 class IsaBnBwd(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("red", C.c_void_p), ("out_red", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
@@ -55,6 +59,7 @@ P_BN = C.POINTER(IsaBnBwd)
 SIGNATURES = {
     "isa_pack_weights": [VP, I32, VP, VP, VP, I32, VP],
     "isa_conv_gemm": [P_T, P_PRO, VP, I32, VP, P_T, I32, I32, VP, I32, VP],
+    "isa_conv_gemm_ep": [P_T, P_PRO, VP, I32, VP, P_T, I32, VP, VP],
     "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP, I64, VP, VP],
     "isa_colsum": [P_T, VP, VP],
     "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],

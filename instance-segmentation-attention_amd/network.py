@@ -26,6 +26,10 @@ class Network:
         cin = x.c
         cout = E.params.shapes[pre + ".conv.3.weight"][0]
         y1 = E.new_act(x.n, x.h, x.w, cin)
+        if E.eval_fusable():                               # eval: BN.4 and the residual ride in the 1x1 conv's epilogue
+            E.dwconv(x, pre + ".conv.0.weight", y1, stats=False)
+            y1 = E.bn(y1, None, pre + ".conv.1", L.ACT_RELU6)
+            return E.conv_bn_eval(y1, pre + ".conv.3.weight", out, pre + ".conv.4", L.ACT_NONE, res=x if cin == cout else None)
         _, s1 = E.dwconv(x, pre + ".conv.0.weight", y1, stats=True)
         y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
         y2 = E.new_act(x.n, x.h, x.w, cout)
@@ -41,6 +45,14 @@ class Network:
         chid = E.params.shapes[pre + ".conv.0.weight"][0]
         cout = E.params.shapes[pre + ".conv.6.weight"][0]
         y1 = E.new_act(x.n, x.h, x.w, chid)
+        if E.eval_fusable() and oscale is None:
+            # eval: expand conv stores ReLU6(BN(.)) (no prologue in the depthwise conv), the project conv applies BN.7 and
+            # the residual in its epilogue (no materialising pass)
+            E.conv_bn_eval(x, pre + ".conv.0.weight", y1, pre + ".conv.1", L.ACT_RELU6)
+            y2 = E.new_act(x.n, x.h, x.w, chid)
+            E.dwconv(y1, pre + ".conv.3.weight", y2, stats=False)
+            y2 = E.bn(y2, None, pre + ".conv.4", L.ACT_RELU6)
+            return E.conv_bn_eval(y2, pre + ".conv.6.weight", out, pre + ".conv.7", L.ACT_NONE, res=x if cin == cout else None)
         _, s1 = E.conv(x, pre + ".conv.0.weight", y1, stats=True)
         y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
         y2 = E.new_act(x.n, x.h, x.w, chid)
