@@ -114,6 +114,55 @@ def test_conv1x1_lazy_prologue(dtype, cin, cout, hw, batch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,hw,batch,taps,with_res,with_pro", [
+    (32, 64, 12, 2, 1, False, False),       # expand conv: activated store
+    (64, 32, 12, 2, 1, True, True),         # project conv: lazy input, BN + residual in the epilogue
+    (256, 128, 9, 3, 1, True, False),       # LDS-tiled path (bf16), ragged M
+    (128, 80, 7, 2, 1, True, True),         # LDS-tiled path, column tail
+    (24, 16, 8, 2, 9, False, False),        # dense 3x3
+])
+def test_conv_eval_epilogue(dtype, cin, cout, hw, batch, taps, with_res, with_pro):
+    """isa_conv_gemm_ep: y = act(scale * conv(pro(x)) + shift) (+ res) - eval-mode BatchNorm, activation and the block's
+    residual add in the conv's output epilogue (Engine.conv_bn_eval), against torch."""
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    k = 3 if taps == 9 else 1
+    w = rand(cout, cin, k, k, seed=1, scale=(taps * cin) ** -0.5)
+    gamma, beta = rand(cout, seed=2).abs() + 0.5, rand(cout, seed=3)
+    rmean, rvar = rand(cout, seed=4) * 0.1, rand(cout, seed=5).abs() + 0.5
+    x = rand(batch, cin, hw, hw + 1, seed=6, scale=2.0)
+    res = rand(batch, cout, hw, hw + 1, seed=7)
+    schema = [("w", w.shape), ("bn.weight", (cout,)), ("bn.bias", (cout,)), ("bn.running_mean", (cout,)),
+              ("bn.running_var", (cout,)), ("bn.num_batches_tracked", ())]
+    ps = ParamStore(schema, "cuda")
+    ps.load_state_dict({"w": w, "bn.weight": gamma, "bn.bias": beta, "bn.running_mean": rmean, "bn.running_var": rvar})
+    eng = Engine(ps, dtype)
+    eng.begin(bn_train=False, record=False)
+    assert eng.eval_fusable()
+    xa = to_act(Act, x, dtype)
+    xt = q(x, dtype)
+    if with_pro:
+        sc, sh = rand(cin, seed=8).abs() + 0.5, rand(cin, seed=9)
+        xa = xa.with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6))
+        xt = torch.clamp(xt * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
+        if dtype == torch.bfloat16:
+            xt = q(xt, dtype)
+    ra = to_act(Act, res, dtype) if with_res else None
+    act = L.ACT_NONE if with_res else L.ACT_RELU6
+    ya = eng.new_act(batch, hw, hw + 1, cout, ld=(cout + 15) // 8 * 8)
+    ya.buf.fill_(5.0)
+    eng.conv_bn_eval(xa, "w", ya, "bn", act, res=ra, taps=taps)
+    torch.cuda.synchronize()
+    ref = F.conv2d(xt, q(w, dtype), padding=k // 2)
+    inv = 1.0 / torch.sqrt(rvar + 1e-5)
+    ref = ref * (gamma * inv)[None, :, None, None] + (beta - rmean * gamma * inv)[None, :, None, None]
+    ref = torch.clamp(ref, 0, 6) if act == L.ACT_RELU6 else ref
+    if with_res:
+        ref = ref + q(res, dtype)
+    assert rel(ya.nchw(), ref) < TOL[dtype]
+    assert float((ya.buf[..., cout:].float() - 5.0).abs().max()) == 0.0     # padding channels untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,hw", [(32, 16, 12), (16, 2, 16), (12, 1, 8), (256, 128, 4)])
 def test_conv3x3_dense(dtype, cin, cout, hw):
     L, Act, Engine, ParamStore, Pro = _gpu()
