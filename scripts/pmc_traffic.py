@@ -7,7 +7,7 @@ bytes = (2*FETCH_SIZE + WRITE_SIZE) KB: on gfx950 FETCH_SIZE counts half of the 
 (MI355X_MICROARCH.md, HBM section); calibration on a known-size launch: profiles/r01_pmc_calibration_conv1x1.txt."""
 import csv, glob, json, re, sys
 
-FAMILIES = [("conv_gemm_kernel", "isa_conv_gemm"), ("conv_wgrad", "isa_conv_wgrad"), ("wgrad_reduce", "isa_conv_wgrad(reduce)"), ("wgrad_fold", "isa_wgrad_defer_flush"),
+FAMILIES = [("conv_gemm_kernel", "isa_conv_gemm"), ("conv_gemm_tiled_kernel", "isa_conv_gemm"), ("conv3x3_tiled_kernel", "isa_conv_gemm"), ("conv_wgrad", "isa_conv_wgrad"), ("wgrad_reduce", "isa_conv_wgrad(reduce)"), ("wgrad_fold", "isa_wgrad_defer_flush"),
             ("pw_bn_bwd_kernel", "isa_conv1x1_bn_backward"), ("dw_bn_bwd_kernel", "isa_dwconv3x3_bn_backward"),
             ("dw2_fwd_kernel", "isa_dwconv3x3"), ("dw_fwd_kernel", "isa_dwconv3x3"), ("bn_bwd_kernel", "isa_bn_bwd"),
             ("materialize_kernel", "isa_affine_act_res"), ("axpy", "isa_axpy")]
