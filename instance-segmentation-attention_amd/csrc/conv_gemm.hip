@@ -84,7 +84,11 @@ __device__ __forceinline__ void frag_set(Frag<T>& f, int j, float x) {
 
 // EP: the output epilogue of isa_conv_gemm_ep is its own instantiation - folded into the common one it cost the training
 // launches 4 % (registers and epilogue code on every launch).
-template <typename T, int NT, int IN_MODE, int OUT_MODE, int PRO, bool EP = false>
+// FAST (1x1, cin == kp): every A-fragment load is unconditional - rows >= M read the last valid row (the epilogue masks
+// them), no channel guards - so the K loop is straight-line code and the compiler's s_waitcnt pass can count: with the
+// guarded, lane-divergent loads of the general path it falls back to vmcnt(0) ahead of every MFMA and any further
+// lookahead (including the next tile's first fragment, requested here before the epilogue) is drained at once.
+template <typename T, int NT, int IN_MODE, int OUT_MODE, int PRO, bool EP = false, bool FAST = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N_BLK = 32 * NT;
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     const T* wg = reinterpret_cast<const T*>(p.w);
     const long wrow = (long)p.taps * p.kp;
 
+    Frag<T> pre;                                                 // FAST: first fragment of the next tile, requested before the epilogue
+    bool have_pre = false;
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const long m = (long)tile * 128 + wave * 32 + r;
         const bool mvalid = m < p.M;
@@ -151,6 +157,98 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
             return xin + (((long)pb * p.xh + sy) * p.xw + sx) * p.ldx + k;
         };
 
+        if constexpr (FAST && IN_MODE == ISA_IN_1X1) {
+            const long mrow = mvalid ? m : p.M - 1;
+            const T* ab = xin + mrow * p.ldx + 16 * hh;
+            auto fload = [&](Frag<T>& f, const T* base, int g) {
+                if constexpr (sizeof(T) == 2) {
+                    f.v[0] = *reinterpret_cast<const bf16x8*>(base + g * 32);
+                    f.v[1] = *reinterpret_cast<const bf16x8*>(base + g * 32 + 8);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f.v[q] = *reinterpret_cast<const f32x4*>(base + g * 32 + 4 * q);
+                }
+                asm volatile("" ::: "memory");                     // keep the request here (LLVM sinks loads to their use)
+            };
+            auto consume = [&](Frag<T>& f, int g, int gl) {
+                const int kq = g * 32 + 16 * hh;
+                if constexpr (HAS_PRO) {
+                    float sc[16], sh[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(pro_tab + kq + 4 * q);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(pro_tab + p.kp + kq + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { sc[4 * q + e] = a[e]; sh[4 * q + e] = b[e]; }
+                    }
+                    float v[16];
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) v[jj] = act_t<ACT>(fmaf(frag_get<T>(f, jj), sc[jj], sh[jj]), p.pro.act);
+                    if (p.pro.bscale) {
+#pragma unroll
+                        for (int jj = 0; jj < 16; ++jj) v[jj] *= p.pro.bscale[(long)pb * p.cin + kq + jj];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) frag_set<T>(f, jj, v[jj]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const T* brow = ldsB + (t * 32 + r) * p.ldb + gl * 32 + 16 * hh;
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x8 b0 = *reinterpret_cast<const bf16x8*>(brow);
+                        bf16x8 b1 = *reinterpret_cast<const bf16x8*>(brow + 8);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[0], b0, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[1], b1, acc[t], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 bq = *reinterpret_cast<const f32x4*>(brow + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.v[q][e], bq[e], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            Frag<T> cur, nxt;
+            if (have_pre) cur = pre; else fload(cur, ab, 0);
+            int g_begin = 0, g_end = 0;
+            for (int g = 0; g < p.total_groups; ++g) {
+                if (g == g_end) {                                  // next weight chunk (one chunk and one staging when resident)
+                    g_begin = g_end;
+                    g_end = min(p.total_groups, g_begin + p.groups_per_chunk);
+                    if (!(resident && loaded)) {
+                        __syncthreads();
+                        constexpr int V = 16 / (int)sizeof(T);
+                        const int len = (g_end - g_begin) * 32;
+                        const int vec_per_row = len / V;
+                        for (int i2 = tid; i2 < N_BLK * vec_per_row; i2 += 256) {
+                            const int row = i2 / vec_per_row, col = (i2 - row * vec_per_row) * V;
+                            f32x4 val = f32x4{0};
+                            if (n0 + row < p.N)
+                                val = *reinterpret_cast<const f32x4*>(wg + (long)(n0 + row) * wrow + g_begin * 32 + col);
+                            *reinterpret_cast<f32x4*>(ldsB + row * p.ldb + col) = val;
+                        }
+                        __syncthreads();
+                        loaded = true;
+                    }
+                }
+                if (g + 1 < p.total_groups) {
+                    fload(nxt, ab, g + 1);
+                    consume(cur, g, g - g_begin);
+                    cur = nxt;
+                } else {
+                    consume(cur, g, g - g_begin);
+                }
+            }
+            const int tn = tile + gridDim.x;
+            have_pre = tn < p.ntiles;
+            if (have_pre) {
+                long mn = (long)tn * 128 + wave * 32 + r;
+                if (mn > p.M - 1) mn = p.M - 1;
+                fload(pre, xin + mn * p.ldx + 16 * hh, 0);
+            }
+        } else {
         Frag<T> cur, nxt;
         int kcur = 0, knxt = 0;
         bool vcur, vnxt = false;
@@ -231,6 +329,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                 }
                 cur = nxt; kcur = knxt; vcur = vnxt;
             }
+        }
+
         }
 
         // ---------------- epilogue: lane r <-> output channel n0+t*32+r -------------------------
@@ -576,6 +676,20 @@ int launch_tiled(const GemmParams& p, bool has_pro, hipStream_t s) {
 
 template <typename T, int NT, int IN_MODE, int OUT_MODE>
 int launch2(const GemmParams& p, bool has_pro, dim3 grid, size_t lds, hipStream_t s) {
+    if constexpr (IN_MODE == ISA_IN_1X1 && OUT_MODE == ISA_OUT_PLAIN) {
+        static const bool fast_ok = !(getenv("ISA_GEMM_FAST") && atoi(getenv("ISA_GEMM_FAST")) == 0);
+        // Measured: on HBM-cold single launches (KBENCH_ROTATE) K = 128 gains (58.7 -> 51.9 us at 128x128), K = 64 is neutral and
+        // K = 32 loses a little (31.0 vs 29.5 us); inside the training step taking it for every eligible launch is the best
+        // setting (same-session A/B, images/s: off 590.8, >= 4 groups 590.2, >= 2 groups 591.1, all 593.0).  With a prologue
+        // the wider tiles would cross an occupancy step, so those stay on the general path.
+        static const int fast_min_groups = getenv("ISA_GEMM_FAST_MIN_GROUPS") ? atoi(getenv("ISA_GEMM_FAST_MIN_GROUPS")) : 1;
+        if (fast_ok && p.cin == p.kp && p.total_groups >= fast_min_groups && !p.ep_scale && (!has_pro || NT == 1)) {
+            if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1, false, true>), grid, dim3(256), lds, s, p);
+            else if (has_pro) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 2, false, true>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 0, false, true>), grid, dim3(256), lds, s, p);
+            return launch_status();
+        }
+    }
     if constexpr (OUT_MODE == ISA_OUT_PLAIN && IN_MODE != ISA_IN_GATHER2) {
         if (p.ep_scale) {
             if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_gemm_kernel<T, NT, IN_MODE, OUT_MODE, 1, true>), grid, dim3(256), lds, s, p);
