@@ -350,6 +350,14 @@ int isa_sdp_attention(const void* q, const void* k, const void* v, const uint8_t
                       float* attn, int32_t bh, int32_t lq, int64_t L, int32_t dk, int32_t dv,
                       float temperature, int32_t dtype, int32_t heads, int32_t mask_per_head,
                       float* ws, int64_t ws_floats, int32_t tile_keys, void* stream);
+/* Backward of isa_sdp_attention (what autograd computes for utils.py:316-327 with dropout off), from the tensors the
+ * forward pass returns: attn (normalised probabilities, head-major rows, zero on masked keys) and out.  dq: fp32
+ * [bh, lq, heads*d], ZERO-INITIALISED by the caller (partials are added atomically); dk, dv: storage dtype, same layout
+ * as k, v, written once.  One streaming pass over K and V.  lq <= 8, d <= 32, lq*d <= 96.  `bh` is the batch (rows of
+ * q), `heads` the interleaved heads per row, exactly as in the forward call. */
+int isa_sdp_attention_bwd(const void* q, const void* k, const void* v, const float* attn, const void* out,
+                          const void* dout, float* dq, void* dk, void* dv, int32_t bh, int32_t lq, int64_t L,
+                          int32_t dk_dim, int32_t dv_dim, float temperature, int32_t dtype, int32_t heads, void* stream);
 /* The `last=True` branch (utils.py:203-209, 310-313): out[(h*b), lq, L] = q k^T (ScaledDotProductAttention) or
  * sigmoid(q k^T) (MultiHeadAttention: sigmoid != 0), no temperature, no softmax; same operand layout. */
 int isa_sdp_scores(const void* q, const void* k, float* out, int32_t b, int32_t heads, int32_t lq, int64_t L,

@@ -47,6 +47,22 @@ def scaled_dot_product_attention(q, k, v, temperature, mask=None, return_attn=Tr
     return out, attn
 
 
+def scaled_dot_product_attention_backward(q, k, v, temperature, out, attn, d_out, heads=1):
+    """Gradients of scaled_dot_product_attention w.r.t. q, k, v (what autograd gives for utils.py:316-327, dropout off)
+    from the forward's own outputs `out` and `attn` (masked keys carry zero probability, so the mask is not needed again).
+    Returns (dq fp32, dk, dv)."""
+    b, lq, dq_ = q.shape
+    Lk = k.shape[1]
+    dk_, dv_ = dq_ // heads, v.shape[2] // heads
+    q, k, v, out, d_out = (t.contiguous() for t in (q, k, v, out, d_out))
+    dq = torch.zeros(b, lq, dq_, dtype=torch.float32, device=q.device)
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    L.check(L.lib().isa_sdp_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(attn.contiguous()), L.ptr(out), L.ptr(d_out),
+                                          L.ptr(dq), L.ptr(dk), L.ptr(dv), b, lq, Lk, dk_, dv_, float(temperature),
+                                          L.dtype_code(q.dtype), heads, L.stream_ptr()), "isa_sdp_attention_bwd")
+    return dq, dk, dv
+
+
 class ScaledDotProductAttention(nn.Module):
     """utils.py:305-329 (constructor signature kept; dropout is an eval-mode no-op)."""
 

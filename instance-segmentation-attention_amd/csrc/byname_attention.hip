@@ -552,6 +552,102 @@ extern "C" int isa_sdp_attention(const void* q, const void* k, const void* v, co
     return launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the streaming attention core (autograd of utils.py:316-327 in eval mode), from what the forward pass
+// already returns: attn (the normalised probabilities, zero on masked keys) and out.
+//   D_q  = dO_q . out_q                      (= sum_j p_qj dP_qj, because out = sum_j p_qj v_j)
+//   dP_qj = dO_q . v_j      dS_qj = p_qj (dP_qj - D_q)
+//   dV_j = sum_q p_qj dO_q  dK_j = sum_q dS_qj q_q / T      dQ_q = sum_j dS_qj k_j / T
+// One pass over K and V: a lane owns keys j, j + stride, ...; dK_j / dV_j are written once, the dQ partials of a lane
+// live in registers (lq * d <= 96), are folded through LDS per workgroup and added to the fp32 dq with one atomic each.
+constexpr int SDPB_MAXQD = 96;
+template <typename T>
+__global__ __launch_bounds__(256) void sdp_bwd_kernel(const T* q, const T* k, const T* v, const float* attn, const T* out, const T* dout,
+                                                      float* dq, T* dk, T* dv, int B, int heads, int lq, long L, int d, int dvd,
+                                                      float inv_t) {
+    __shared__ float sq[SDPB_MAXQD], sdo[SDPB_MAXQD], sD[8];
+    __shared__ float sS[8][256];                                  // dS of this chunk's keys, per query
+    __shared__ float sK[256][33];                                 // the chunk's keys (fp32, +1 pad: conflict-free column reads)
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int ldq = heads * d, ldv = heads * dvd;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < lq * d; i += 256) sq[i] = st<T>::ld(q + ((long)b * lq + i / d) * ldq + h * d + i % d);
+    for (int i = tid; i < lq * dvd; i += 256) sdo[i] = st<T>::ld(dout + ((long)b * lq + i / dvd) * ldv + h * dvd + i % dvd);
+    __syncthreads();
+    if (tid < lq) {
+        float s = 0.f;
+        for (int e = 0; e < dvd; ++e) s += sdo[tid * dvd + e] * st<T>::ld(out + ((long)b * lq + tid) * ldv + h * dvd + e);
+        sD[tid] = s;
+    }
+    __syncthreads();
+    const float* arow = attn + ((long)h * B + b) * lq * L;          // attn rows are head-major ((h*B + b)*lq + q)
+    const int qi_b = tid / d, e_b = tid - qi_b * d;                  // phase-B role: one (query, channel) of dQ
+    float acc = 0.f;
+    for (long j0 = (long)blockIdx.x * 256; j0 < L; j0 += (long)gridDim.x * 256) {
+        const long j = j0 + tid;
+        const bool live = j < L;
+        float kj[32], vj[32], dkj[32], dvj[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            kj[e] = (live && e < d) ? st<T>::ld(k + ((long)b * L + j) * ldq + h * d + e) : 0.f;
+            vj[e] = (live && e < dvd) ? st<T>::ld(v + ((long)b * L + j) * ldv + h * dvd + e) : 0.f;
+            dkj[e] = 0.f; dvj[e] = 0.f;
+            sK[tid][e] = kj[e];
+        }
+        for (int qi = 0; qi < lq; ++qi) {
+            const float pj = live ? arow[(long)qi * L + j] : 0.f;
+            float dP = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) if (e < dvd) dP += sdo[qi * dvd + e] * vj[e];
+            const float dS = pj * (dP - sD[qi]) * inv_t;
+            sS[qi][tid] = dS;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                if (e < dvd) dvj[e] += pj * sdo[qi * dvd + e];
+                if (e < d) dkj[e] += dS * sq[qi * d + e];
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                if (e < d) st<T>::stv(dk + ((long)b * L + j) * ldq + h * d + e, dkj[e]);
+                if (e < dvd) st<T>::stv(dv + ((long)b * L + j) * ldv + h * dvd + e, dvj[e]);
+            }
+        }
+        __syncthreads();
+        if (tid < lq * d) {
+#pragma unroll 8
+            for (int jj = 0; jj < 256; ++jj) acc += sS[qi_b][jj] * sK[jj][e_b];
+        }
+        __syncthreads();
+    }
+    if (tid < lq * d && acc != 0.f) atomicAdd(dq + ((long)b * lq + qi_b) * ldq + h * d + e_b, acc);
+}
+
+extern "C" int isa_sdp_attention_bwd(const void* q, const void* k, const void* v, const float* attn, const void* out,
+                                     const void* dout, float* dq, void* dk, void* dv, int32_t bh, int32_t lq, int64_t L,
+                                     int32_t dkd, int32_t dvd, float temperature, int32_t dtype, int32_t heads, void* stream) {
+    if (!q || !k || !v || !attn || !out || !dout || !dq || !dk || !dv) return ISA_EINVAL;
+    if (bh <= 0 || lq <= 0 || lq > 8 || L <= 0 || dkd <= 0 || dkd > 32 || dvd <= 0 || dvd > 32 || heads <= 0) return ISA_EINVAL;
+    if (lq * dkd > SDPB_MAXQD || lq * dvd > SDPB_MAXQD || !(temperature > 0.f)) return ISA_EINVAL;
+    long gx = (L + 255) / 256;
+    const long cap = (2048 + (long)bh * heads - 1) / ((long)bh * heads);      // ~8 workgroups per CU in total (44 KB of LDS each)
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)(bh * heads));
+    hipStream_t s = as_stream(stream);
+    const float it = 1.f / temperature;
+#define SDPB(T) hipLaunchKernelGGL(sdp_bwd_kernel<T>, grid, dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, attn, (const T*)out, \
+                                   (const T*)dout, dq, (T*)dk, (T*)dv, (int)bh, (int)heads, (int)lq, (long)L, (int)dkd, (int)dvd, it)
+    if (dtype == ISA_F32) SDPB(float);
+    else if (dtype == ISA_BF16) SDPB(bf16_t);
+    else if (dtype == ISA_F16) SDPB(f16_t);
+    else return ISA_EINVAL;
+#undef SDPB
+    return launch_status();
+}
+
 extern "C" int isa_sdp_scores(const void* q, const void* k, float* out, int32_t b, int32_t heads, int32_t lq, int64_t L,
                               int32_t d, int32_t dtype, int32_t sigmoid, void* stream) {
     if (!q || !k || !out || b <= 0 || heads < 1 || lq <= 0 || L <= 0 || d <= 0) return ISA_EINVAL;

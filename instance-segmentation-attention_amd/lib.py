@@ -117,6 +117,7 @@ SIGNATURES = {
     "isa_sqnorm": [VP, I64, F, VP, VP],
     "isa_adadelta": [VP, VP, VP, VP, I64, F, F, F, F, VP, F, F, VP, VP],
     "isa_sdp_attention": [VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, I32, I32, VP, I64, I32, VP],
+    "isa_sdp_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, I32, I32, I64, I32, I32, F, I32, I32, VP],
     "isa_sdp_scores": [VP, VP, VP, I32, I32, I32, I64, I32, I32, I32, VP],
     "isa_linear_ln": [VP, VP, VP, VP, VP, VP, F, I32, I32, I32, VP, VP],
     "isa_instance_norm_res": [P_T, P_T, P_T, F, VP, VP],

@@ -113,3 +113,41 @@ def test_scale_pd_attention_whole_operator():
     out = m(t("local/qk_in").cuda(), t("local/v_in").cuda(), t("local/nomask").cuda())
     torch.cuda.synchronize()
     assert rel(out, t("local/out")) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("b,heads,lq,L,d", [(3, 1, 1, 1000, 12), (2, 2, 3, 4097, 12), (1, 1, 6, 70001, 12), (2, 1, 2, 300, 32),
+                                            (1, 1, 4, 513, 16)])
+def test_scaled_dot_product_attention_backward(dtype, tol, b, heads, lq, L, d):
+    """isa_sdp_attention_bwd against torch autograd (float64 on the CPU) of the reference's formula
+    softmax(mask(q k^T / T)) v, from the forward pass's own outputs; masked keys, interleaved heads, ragged lengths."""
+    A = ops()
+    if d != 12 and dtype == torch.float16:
+        pytest.skip("the forward pass streams f16 only at the reference's head width (12)")
+    g = torch.Generator().manual_seed(L + lq)
+    q = torch.randn(b, lq, heads * d, generator=g)
+    k, v = torch.randn(b, L, heads * d, generator=g), torch.randn(b, L, heads * d, generator=g)
+    # with 70 001 keys a probability is ~1e-5 and dK / dV land in f16's subnormal range: scale the incoming gradient the way
+    # a loss scaler would (the backward pass is linear in it)
+    d_out = torch.randn(b, lq, heads * d, generator=g) * (1024.0 if L > 10000 else 1.0)
+    mask = torch.rand(b, lq, L, generator=g) < 0.3
+    temp = d ** 0.5
+    qd, kd, vd, dod = (t.cuda().to(dtype) for t in (q, k, v, d_out))
+    out, attn = A.scaled_dot_product_attention(qd, kd, vd, temp, mask.cuda(), heads=heads)
+    dq, dk, dv = A.scaled_dot_product_attention_backward(qd, kd, vd, temp, out, attn, dod, heads=heads)
+    torch.cuda.synchronize()
+    # reference: per head, float64 autograd on the storage-rounded operands
+    q64, k64, v64 = (t.float().cpu().double().requires_grad_(True) for t in (qd, kd, vd))
+    do64 = dod.float().cpu().double()
+    outs = []
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        s = (q64[..., sl] @ k64[..., sl].transpose(1, 2) / temp).masked_fill(mask, float("-inf"))
+        outs.append(torch.softmax(s, 2) @ v64[..., sl])
+    (torch.cat(outs, 2) * do64).sum().backward()
+    # the saved forward output enters through D = dO . out: over 70 001 keys `out` is a mean of ~49 000 values (|out| ~ 1e-2)
+    # and its storage rounding (5e-3 relative to its largest element in f16 and bf16 alike, measured) bounds dK / dV there
+    bound = max(tol, 1e-4) if (dtype == torch.float32 or L <= 10000) else max(tol, 1e-2)
+    assert rel(dq, q64.grad) < bound
+    assert rel(dk.float(), k64.grad) < bound
+    assert rel(dv.float(), v64.grad) < bound
