@@ -47,10 +47,18 @@ typedef struct isa_tensor {
     int32_t c;      /* channels in the view */
     int32_t ld;     /* pixel stride in elements (>= c) */
     int32_t dtype;  /* ISA_F32 | ISA_BF16 */
+    int32_t groups; /* statistic groups G (0 or 1: one group).  G > 1: the n images are G consecutive groups of n/G
+                       images with separate train-mode BatchNorm statistics (the decoder iterations of attenet2.py:384-399
+                       batched into one pass share weights but not batch statistics).  Every per-channel array that
+                       accompanies a grouped tensor then carries a leading [G] dimension: isa_pro.scale/shift [G][c],
+                       stats [G][ISA_STAT_REPLICAS][2N], isa_bn_bwd scale/shift/mean/invstd [G][c] and red/out_red
+                       [G][ISA_STAT_REPLICAS][2c]; per-image arrays (bscale, oscale) are [n][c] as before and parameter
+                       gradients (dw, dbias, dgamma, dbeta) are sums over all groups.  Entry points without per-channel
+                       statistics or constants ignore the field. */
 } isa_tensor;
 
 typedef struct isa_pro {       /* lazy-input prologue; all pointers may be NULL */
-    const float* scale;        /* [c]   */
+    const float* scale;        /* [c]   ([G][c] for a grouped tensor, see isa_tensor.groups) */
     const float* shift;        /* [c]   */
     const float* bscale;       /* [n,c] per-image channel multiplier (Dropout2d mask, SE gate) */
     int32_t      act;          /* ISA_ACT_* applied after the affine, before bscale */
@@ -194,11 +202,16 @@ int isa_slab_arena_flush(isa_slab_arena* a, void* stream, int32_t* n_folds, int6
 /* ---- BatchNorm2d pieces (torch.nn.BatchNorm2d train/eval semantics) --------------------------
  * finalize: stats[2C] (sum, sumsq over `count` values) -> scale/shift (and mean/invstd for the
  * backward); updates running_mean/var (momentum, unbiased var) when running_* != NULL.
- * eval mode: pass stats == NULL and scale/shift are derived from running_*.                    */
+ * eval mode: pass stats == NULL and scale/shift are derived from running_*.
+ * groups G > 1 (isa_tensor.groups): stats [G][ISA_STAT_REPLICAS][2c] and `count` values per group ->
+ * scale/shift/mean/invstd [G][c]; the running statistics take the G updates in group order, as the reference's
+ * decoder iterations pass through the same module one after the other (attenet2.py:384-399).
+ * repeat R > 1: every update is applied R times (a sub-network whose input does not depend on the iteration is
+ * evaluated once here where the reference evaluates it R times with identical batch statistics).           */
 int isa_bn_finalize(const float* stats, float count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* mean, float* invstd, int32_t c,
-                    void* stream);
+                    int32_t groups, int32_t repeat, void* stream);
 /* Running-statistics updates of `n` train-mode layers, applied in array order by ONE launch per 64 layers: what
  * isa_bn_finalize does to running_mean/var when it is given them.  For statistics produced on another HIP stream
  * than the one that must own the update order (the decoder iterations run concurrently, attenet2.py:384-399 runs
@@ -223,7 +236,9 @@ int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const float* sca
 
 /* ---- materialise a lazy tensor: out = pro(x) (+ res)  (residual adds of Inverted*Residual,
  * F.dropout2d, torch.cat placement) and its backward pieces ----------------------------------- */
-/* out = (pro(x) (+res) (+res2)) * oscale[n,c]   (oscale: F.dropout2d after a residual sum) */
+/* out = (pro(x) (+res) (+res2)) * oscale[n,c]   (oscale: F.dropout2d after a residual sum).
+ * Broadcast form: out has G groups (out->groups = G, out->n = G * x->n) while x, res hold ONE group: every output
+ * group g is (pro(x) + res (+ res2[g])) * oscale[g] - the Dropout2d that follows an iteration-independent block. */
 int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
                        const isa_tensor* res2, const float* oscale, const isa_tensor* out,
                        void* stream);
@@ -272,7 +287,10 @@ int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, const float* me
 /* HardAttentionLayer softmax for the selected instance of each image (utils.py:648-655 + the
  * gather of attenet2.py:342-343): alpha[b,:] = softmax over pixels of ins[b, idx[b]] */
 int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
-                    int64_t L, float* alpha, float* rowstat /*[n,2]*/, void* stream);
+                    int64_t L, float* alpha, float* rowstat /*[n,2]*/, int32_t nsrc, void* stream);
+/* `nsrc` (here and in isa_pool_target / isa_ins_softmax_bwd; 0 = n): the n rows are n/nsrc decoder iterations over the same
+ * nsrc images - row b reads merge / ins of image b % nsrc with its own idx[b], so the fronts of all iterations
+ * (attenet2.py:384-399) are one launch.  isa_concat_aux's `mask_n` is the same for its shared mask_all map. */
 /* DecoderLayer.sample (attenet2.py:304-324): first argmax per row, on device.  race == NULL: the eval branch
  * (argmax of alpha).  race != NULL ([n, L] draws from Exp(1)): argmax of alpha / race = one draw from
  * Multinomial(alpha), the training branch (torch.multinomial's own single-sample form). */
@@ -285,10 +303,10 @@ int isa_dropout_mask(const float* u, int64_t n, float keep, float* out, void* st
 int isa_softmax_nchw(const isa_tensor* x, float* out, void* stream);
 /* UpDecoderLayer.resize (utils.py:841-846): f x f max-pool of the instance plane / of an fp32 map */
 int isa_pool_target(const int64_t* ins, const int32_t* idx, const float* src, int32_t nobj, int32_t n,
-                    int32_t H, int32_t W, int32_t f, float* out, void* stream);
+                    int32_t H, int32_t W, int32_t f, float* out, int32_t nsrc, void* stream);
 /* mask_all + conPosition channels (utils.py:1027-1045,1085) written into a concat slice */
 int isa_concat_aux(const isa_tensor* dst, const float* mask_all, const int32_t* s_t, int32_t W_full,
-                   int32_t f, int32_t nb, void* stream);
+                   int32_t f, int32_t nb, int32_t mask_n, void* stream);
 /* UpAttenLayer.Mask (utils.py:1047-1056): out = up * softmax2(bilinear_x2(pred))[1] */
 int isa_gate(const isa_tensor* up, const isa_tensor* pred, const isa_tensor* out, float* gmap, void* stream);
 /* per-image sums for dice / focal / CE of a 2-class prediction (dice.py:10-51, multi_loss.py:27-42):
@@ -299,17 +317,20 @@ int isa_mask_loss_sums(const isa_tensor* pred, const float* target, const int64_
 /* ---- losses and hand-derived backward of the head (the reference relies on autograd) ------------
  * isa_head_loss: attenet2.py:239-290 on device (no host sync): per-level gradient coefficients,
  * REINFORCE advantage with the EMA baseline (device scalar), and scal[0..3] += {ins_cost without the
- * NaN entropy term (attenet2.py:77, zero gradient), criterion, ins_ce_loss, ins_dice_loss}/max_iter. */
+ * NaN entropy term (attenet2.py:77, zero gradient), criterion, ins_ce_loss, ins_dice_loss}/max_iter.
+ * iters > 1: the rows of `iters` decoder iterations at once - sums [5][iters*B][8], alpha / s_t / adv [iters*B], coef
+ * [5][iters*B][4] - processed in iteration order, the EMA baseline carried from one to the next (attenet2.py:266). */
 int isa_head_loss(const float* sums /*[5][B][8]*/, const float* alpha, const int32_t* s_t, int64_t L, int32_t B,
                   const float* level_w /*host[5]*/, float ce_weight, float lambda_l, float lambda_r, float inv_iter,
                   float* baseline, int32_t training, float* coef /*[5][B][4]*/, float* adv /*[B]*/,
-                  float* scal /*[4]*/, void* stream);
+                  float* scal /*[4]*/, int32_t iters, void* stream);
 /* trainer-side CE + Dice on the semantic logits (model.py:255-269): scal = {ce, dice}, coef[B][4] */
 int isa_sem_loss(const float* sums /*[B][8]*/, int32_t B, float* coef, float* scal, void* stream);
 int isa_mask_loss_grad(const isa_tensor* pred, const float* target, const int64_t* onehot, const float* coef /*[B][4]*/,
                        const isa_tensor* dpred, int32_t accumulate, void* stream);
 int isa_ins_softmax_bwd(const float* alpha, const int64_t* ins, const int32_t* idx, const int32_t* s_t,
-                        const float* adv, int32_t n, int32_t nobj, int64_t L, float* dmerge, void* stream);
+                        const float* adv, int32_t n, int32_t nobj, int64_t L, float* dmerge /*[nsrc, L]*/, int32_t nsrc,
+                        void* stream);
 int isa_maskbn_bwd(const isa_tensor* e, const float* sem, const float* dmerge, const float* mean_var,
                    const float* w, float eps, const float* am, int32_t train, float* red4 /*zeroed*/, float* k2,
                    float* dw, float* db, const isa_tensor* de, int32_t accumulate, void* stream);
@@ -324,7 +345,8 @@ int isa_gate_bwd(const isa_tensor* dout, const isa_tensor* up, const float* gmap
 int isa_se_bwd(const isa_tensor* dxa, const isa_tensor* x, const float* gate, const float* hid, const float* mean,
                const float* w1, const float* w2, int32_t hidden, float* dg /*zeroed [n*c]*/, float* dmean /*[n*c]*/,
                float* dw1, float* db1, float* dw2, float* db2, const isa_tensor* dx, int32_t accumulate, void* stream);
-/* dst (+)= src * s[n,c]  (Dropout2d backward on a residual sum) */
+/* dst (+)= src * s[n,c]  (Dropout2d backward on a residual sum).  src may hold G * dst.n images (a tensor that was
+ * broadcast to G statistic groups, each with its own per-image scale): dst[b] (+)= sum_g src[g*n+b] * s[g*n+b]. */
 int isa_scale_bc(const isa_tensor* src, const float* s_bc, const isa_tensor* dst, int32_t accumulate, void* stream);
 /* optimizer on the flat parameter buffer (model.py:145-166,273-278): out += sum (g*scale)^2, then
  * clip_grad_norm_(max_norm) + Adadelta(lr, rho, eps, weight_decay) in one pass.  lr_dev (optional, device float[1])

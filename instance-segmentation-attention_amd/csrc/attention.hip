@@ -266,12 +266,13 @@ __global__ __launch_bounds__(256) void maskbn_apply_pool_kernel(View e, const fl
 }
 
 // ---- a9/a10: alpha[b,:] = softmax over the pixels of instance idx[b] of merge[b,:] (0 if empty) ---
+// nsrc: images behind the rows - row b reads image b % nsrc (all decoder iterations in one launch: rows [it*nsrc + image])
 __global__ __launch_bounds__(1024) void ins_softmax_kernel(const float* merge, const int64_t* ins, const int32_t* idx,
-                                                           int nobj, long L, float* alpha, float* rowstat) {
+                                                           int nobj, long L, float* alpha, float* rowstat, int nsrc) {
     __shared__ float sh[16];
-    const int b = blockIdx.x;
-    const int64_t* plane = ins + ((long)b * nobj + idx[b]) * L;
-    const float* z = merge + (long)b * L;
+    const int b = blockIdx.x, bi = b % nsrc;
+    const int64_t* plane = ins + ((long)bi * nobj + idx[b]) * L;
+    const float* z = merge + (long)bi * L;
     float mx = -INFINITY;
     for (long p = threadIdx.x; p < L; p += 1024) if (plane[p] != 0) mx = fmaxf(mx, z[p]);
     mx = block_max(mx, sh);
@@ -313,19 +314,20 @@ __global__ __launch_bounds__(1024) void row_argmax_kernel(const float* a, const 
 
 // ---- a12: pyramid targets: tgt[b,y,x] = max over the f x f block of plane ins[b, idx[b]] ---------
 // (idx == nullptr: `src` is an fp32 map instead, used for the semantic mask `mask_all`)
+// nsrc: images behind the n output maps - map b reads image b % nsrc (all decoder iterations, or copies of one map)
 __global__ __launch_bounds__(256) void pool_target_kernel(const int64_t* ins, const int32_t* idx, const float* src,
-                                                          int nobj, int n, int H, int W, int f, float* out) {
+                                                          int nobj, int n, int H, int W, int f, float* out, int nsrc) {
     const int h = H / f, w = W / f;
     const long total = (long)n * h * w;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int x = (int)(i % w); const long q = i / w; const int y = (int)(q % h); const int b = (int)(q / h);
         float v = 0.f;
         if (idx) {
-            const int64_t* plane = ins + ((long)b * nobj + idx[b]) * H * W;
+            const int64_t* plane = ins + ((long)(b % nsrc) * nobj + idx[b]) * H * W;
             for (int dy = 0; dy < f; ++dy)
                 for (int dx = 0; dx < f; ++dx) if (plane[(long)(y * f + dy) * W + x * f + dx] != 0) v = 1.f;
         } else {
-            const float* plane = src + (long)b * H * W;
+            const float* plane = src + (long)(b % nsrc) * H * W;
             v = -INFINITY;
             for (int dy = 0; dy < f; ++dy)
                 for (int dx = 0; dx < f; ++dx) v = fmaxf(v, plane[(long)(y * f + dy) * W + x * f + dx]);
@@ -338,14 +340,14 @@ __global__ __launch_bounds__(256) void pool_target_kernel(const int64_t* ins, co
 // (utils.py:1027-1045 conPosition + the mask_all cat at :1085).  s_t is the flat full-res index.
 template <typename T>
 __global__ __launch_bounds__(256) void concat_aux_kernel(View dst, const float* mask_all, const int32_t* s_t,
-                                                         int W_full, int f, int nb) {
+                                                         int W_full, int f, int nb, int mask_n) {
     const int naux = 2 * nb + 2;
     const long total = (long)dst.n * dst.h * dst.w * naux;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % naux); const long pix = i / naux;
         const int x = (int)(pix % dst.w); const long q = pix / dst.w; const int y = (int)(q % dst.h); const int b = (int)(q / dst.h);
         float v;
-        if (ch == 0) v = mask_all[pix];
+        if (ch == 0) v = mask_all[((long)(b % mask_n) * dst.h + y) * dst.w + x];       // mask_n images behind dst.n (iterations share it)
         else {
             const int s = s_t[b], r = s / W_full, c = s % W_full;
             const bool here = (r / f == y) && (c / f == x);
@@ -500,9 +502,11 @@ extern "C" int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, cons
 }
 
 extern "C" int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
-                               int64_t L, float* alpha, float* rowstat, void* stream) {
+                               int64_t L, float* alpha, float* rowstat, int32_t nsrc, void* stream) {
     if (!merge || !ins || !idx || !alpha || n <= 0) return ISA_EINVAL;
-    hipLaunchKernelGGL(ins_softmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), merge, ins, idx, nobj, (long)L, alpha, rowstat);
+    if (nsrc <= 0) nsrc = n;
+    if (n % nsrc) return ISA_EINVAL;
+    hipLaunchKernelGGL(ins_softmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), merge, ins, idx, nobj, (long)L, alpha, rowstat, nsrc);
     return launch_status();
 }
 
@@ -562,20 +566,24 @@ extern "C" int isa_softmax_nchw(const isa_tensor* x, float* out, void* stream) {
 }
 
 extern "C" int isa_pool_target(const int64_t* ins, const int32_t* idx, const float* src, int32_t nobj, int32_t n,
-                               int32_t H, int32_t W, int32_t f, float* out, void* stream) {
-    if ((!ins && !src) || (ins && !idx) || !out || f < 1 || H % f || W % f) return ISA_EINVAL;
+                               int32_t H, int32_t W, int32_t f, float* out, int32_t nsrc, void* stream) {
+    if ((!ins && !src) || (ins && !idx) || !out || f < 1 || H % f || W % f || n <= 0) return ISA_EINVAL;
+    if (nsrc <= 0) nsrc = n;
+    if (n % nsrc) return ISA_EINVAL;
     const int grid = grid_cap(cdiv((long)n * (H / f) * (W / f), 256));
-    hipLaunchKernelGGL(pool_target_kernel, dim3(grid), dim3(256), 0, as_stream(stream), ins, ins ? idx : nullptr, src, nobj, n, H, W, f, out);
+    hipLaunchKernelGGL(pool_target_kernel, dim3(grid), dim3(256), 0, as_stream(stream), ins, ins ? idx : nullptr, src, nobj, n, H, W, f, out, nsrc);
     return launch_status();
 }
 
 extern "C" int isa_concat_aux(const isa_tensor* dst, const float* mask_all, const int32_t* s_t, int32_t W_full,
-                              int32_t f, int32_t nb, void* stream) {
+                              int32_t f, int32_t nb, int32_t mask_n, void* stream) {
     if (!tensor_ok(dst, 1) || !mask_all || !s_t || dst->c != 2 * nb + 2) return ISA_EINVAL;
+    if (mask_n <= 0) mask_n = dst->n;
+    if (dst->n % mask_n) return ISA_EINVAL;
     const int grid = grid_cap(cdiv((long)dst->n * dst->h * dst->w * dst->c, 256));
     DISPATCH_T(dst->dtype,
-        hipLaunchKernelGGL(concat_aux_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(dst), mask_all, s_t, W_full, f, nb),
-        hipLaunchKernelGGL(concat_aux_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(dst), mask_all, s_t, W_full, f, nb));
+        hipLaunchKernelGGL(concat_aux_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(dst), mask_all, s_t, W_full, f, nb, mask_n),
+        hipLaunchKernelGGL(concat_aux_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(dst), mask_all, s_t, W_full, f, nb, mask_n));
     return launch_status();
 }
 

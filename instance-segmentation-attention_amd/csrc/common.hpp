@@ -186,6 +186,24 @@ __device__ __forceinline__ float fold_stride(float v, int cg, int lane) {
     return v;
 }
 
+// ---- statistic groups (isa_tensor.groups) -----------------------------------------------------
+// A grouped launch is G independent sub-problems of n/G images each that differ only in their BatchNorm statistics
+// and constants.  A workgroup works for ONE group: workgroups [g*per, (g+1)*per) of gridDim.x belong to group g
+// (the host rounds gridDim.x to a multiple of G).  The kernel offsets its tensor pointers by g sub-problems, its
+// per-channel pointers by g arrays, and then runs its usual loops with (bx, nbx) in place of (blockIdx.x, gridDim.x);
+// slab and replica indices keep the absolute blockIdx.x.
+struct GroupSel { int g, bx, nbx; };
+__device__ __forceinline__ GroupSel group_sel(int G) {
+    if (G <= 1) return GroupSel{0, (int)blockIdx.x, (int)gridDim.x};
+    const int per = (int)gridDim.x / G;
+    const int g = (int)blockIdx.x / per;
+    return GroupSel{g, (int)blockIdx.x - g * per, per};
+}
+template <typename P> __device__ __forceinline__ P* goff(P* p, long off) { return p ? p + off : p; }
+static inline int tensor_groups(const isa_tensor* t) { return (t && t->groups > 1) ? t->groups : 1; }
+// grid of a grouped launch: a multiple of G, at least G
+static inline long group_grid(long gx, int G) { if (G <= 1) return gx < 1 ? 1 : gx; gx = gx / G * G; return gx < G ? G : gx; }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_cap(long blocks, int cap = 256 * 8) { return (int)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap); }
 

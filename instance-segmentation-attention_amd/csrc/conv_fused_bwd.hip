@@ -28,6 +28,7 @@ struct PwParams {
     const float *xsc, *xsh, *xmu, *xis; int xact; float* xred;
     int accumulate; float* ws;
     const bf16_t* addend; int lda;       // optional: dx += addend (the residual branch's gradient, saves its axpy pass)
+    int G;                               // statistic groups: M is per group (common.hpp)
 };
 
 // XMODE 0: plain x; 1: x = relu6(scale*x+shift) with BN(x) sums produced; 2: runtime prologue, sums if p.xred
@@ -46,6 +47,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int r = lane & 31, hh = lane >> 5;
     char* sD = ldsb + wave * SLAB;
     char* sX = sD + PMB * SN;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                                  // this workgroup's statistic group: rows [g*M, (g+1)*M)
+        const long gm = (long)gs.g * p.M;
+        p.g += gm * p.ldg; p.y += gm * p.ldy; p.x += gm * p.ldx; p.dx += gm * p.lddx;
+        if (p.addend) p.addend += gm * p.lda;
+        p.ysc += gs.g * p.N; p.ysh += gs.g * p.N; p.ymu += gs.g * p.N; p.yis += gs.g * p.N; p.yred += gs.g * ISA_STAT_R * 2 * p.N;
+        p.xsc = goff(p.xsc, (long)gs.g * p.K); p.xsh = goff(p.xsh, (long)gs.g * p.K); p.xmu = goff(p.xmu, (long)gs.g * p.K);
+        p.xis = goff(p.xis, (long)gs.g * p.K); p.xred = goff(p.xred, (long)gs.g * ISA_STAT_R * 2 * p.K);
+    }
     const bool want_xred = XMODE == 1 || (XMODE == 2 && p.xred != nullptr);
 
     // ---- per-lane constants: a lane keeps ONE 8-channel group of each operand
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < ISA_STAT_R; ++r) { r0 += p.yred[r * 2 * p.N + cn]; r1 += p.yred[r * 2 * p.N + p.N + cn]; }
         cst[3 * 64 + tid] = p.yis[cn] * (r1 * p.ycnt_inv);                    // invstd * mean(g' * yhat)
         cst[4 * 64 + tid] = r0 * p.ycnt_inv;                                  // mean(g')
-        if (blockIdx.x == 0 && tid < p.N) {                                   // BN(y) parameter gradients
+        if (gs.bx == 0 && tid < p.N) {                                        // BN(y) parameter gradients (per group)
             if (p.ydgamma) atomicAdd(p.ydgamma + tid, r1);
             if (p.ydbeta) atomicAdd(p.ydbeta + tid, r0);
         }
@@ -159,8 +169,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    const long stride = (long)gridDim.x * 4;
-    long chunk = (long)blockIdx.x * 4 + wave;
+    const long stride = (long)gs.nbx * 4;
+    long chunk = (long)gs.bx * 4 + wave;
     if (chunk < nchunks) fetch(chunk);
     for (; chunk < nchunks; chunk += stride) {
         stash(chunk);
@@ -307,12 +317,13 @@ int launch_inst(PwParams& p, long ws_floats, isa_slab_arena* sa, hipStream_t s) 
     constexpr size_t lds = slab > redb ? slab : redb;
     const long nchunks = (p.M + 31) / 32;
     const long slabf = (long)TN * TK * 1024 + TN * 32;
-    long gx = (nchunks + 3) / 4;
+    long gx = (nchunks + 3) / 4 * p.G;
     if (gx > 256 * 2) gx = 256 * 2;                                  // 2 resident workgroups per CU; fewer slabs to reduce
     if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / slabf;
-    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
+    if (ws_cap < p.G) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
+    gx = group_grid(gx, p.G);
     hipLaunchKernelGGL((pw_bn_bwd_kernel<TN, TK, YACT, XMODE>), dim3((unsigned)gx), dim3(256), lds, s, p);
     if (launch_status() != ISA_OK) return ISA_ELAUNCH;
     return wgrad_slab_reduce_launch(p.ws, p.dw, nullptr, (int)gx, TN, TK, p.N, p.K, 1, sa, s);
@@ -353,7 +364,9 @@ extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y,
     PwParams p{};
     p.g = (const bf16_t*)g->data; p.y = (const bf16_t*)y->data; p.x = (const bf16_t*)x->data; p.dx = (bf16_t*)dx->data;
     p.w = w; p.dw = dw; p.N = N; p.K = K; p.ldg = g->ld; p.ldy = y->ld; p.ldx = x->ld; p.lddx = dx->ld;
-    p.M = (long)g->n * g->h * g->w;
+    p.G = tensor_groups(g);                                       // BN(y) constants and sums are per statistic group
+    if (g->n % p.G) return ISA_EINVAL;
+    p.M = (long)(g->n / p.G) * g->h * g->w;
     p.ysc = ybn->scale; p.ysh = ybn->shift; p.ymu = ybn->mean; p.yis = ybn->invstd; p.yred = ybn->red;
     p.ycnt_inv = 1.f / ybn->count; p.yact = ybn->act; p.ydgamma = ybn->dgamma; p.ydbeta = ybn->dbeta;
     p.xsc = xp.scale; p.xsh = xp.shift; p.xact = xp.act;

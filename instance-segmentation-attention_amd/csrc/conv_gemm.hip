@@ -38,6 +38,7 @@ struct GemmParams {
     int ntiles;
     // optional output epilogue (isa_conv_gemm_ep): y = act(ep_scale[n] * (conv + bias) + ep_shift[n]) + res
     const float *ep_scale, *ep_shift; int ep_act; const void* res; int ldres;
+    int G;                                      // statistic groups (1x1 plain only): M, ntiles are per group (common.hpp)
 };
 
 template <typename T> struct Frag;      // 16 contiguous channels of one pixel
@@ -97,6 +98,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int n0 = blockIdx.y * N_BLK;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                 // this workgroup's statistic group: rows [g*M, (g+1)*M) and its constants
+        p.x = reinterpret_cast<const T*>(p.x) + (long)gs.g * p.M * p.ldx;
+        p.y = reinterpret_cast<T*>(p.y) + (long)gs.g * p.M * p.ldy;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.cin); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.cin);
+        p.pro.bscale = goff(p.pro.bscale, (long)gs.g * (p.M / ((long)p.mh * p.mw)) * p.cin);
+        p.stats = goff(p.stats, (long)gs.g * ISA_STAT_R * 2 * p.N);
+    }
     // LDS carve: [B tile][pro table][4 x stage]
     T* ldsB = reinterpret_cast<T*>(smem);
     const int b_bytes = (N_BLK * p.ldb * (int)sizeof(T) + 15) & ~15;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 
     Frag<T> pre;                                                 // FAST: first fragment of the next tile, requested before the epilogue
     bool have_pre = false;
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int tile = gs.bx; tile < p.ntiles; tile += gs.nbx) {
         const long m = (long)tile * 128 + wave * 32 + r;
         const bool mvalid = m < p.M;
         int pb = 0, py = 0, px = 0;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                     consume(cur, g, g - g_begin);
                 }
             }
-            const int tn = tile + gridDim.x;
+            const int tn = tile + gs.nbx;
             have_pre = tn < p.ntiles;
             if (have_pre) {
                 long mn = (long)tn * 128 + wave * 32 + r;
@@ -453,7 +462,15 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                                    // statistic group (see conv_gemm_kernel)
+        p.x = reinterpret_cast<const bf16_t*>(p.x) + (long)gs.g * p.M * p.ldx;
+        p.y = reinterpret_cast<bf16_t*>(p.y) + (long)gs.g * p.M * p.ldy;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.kp); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.kp);
+        p.pro.bscale = goff(p.pro.bscale, (long)gs.g * (p.M / ((long)p.mh * p.mw)) * p.cin);
+        p.stats = goff(p.stats, (long)gs.g * ISA_STAT_R * 2 * p.N);
+    }
+    const int tm = gs.bx / tiles_n, tn = gs.bx - tm * tiles_n;
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN, K = p.kp;
     const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.x);
@@ -652,7 +669,7 @@ int launch_tiled_ep(const GemmParams& p, bool has_pro, hipStream_t s) {
     constexpr int BN = 64 * WN, LDT = 72;
     const size_t tiles = 2 * (size_t)(128 + BN) * LDT * 2;
     const size_t lds = tiles + (has_pro ? 2 * (size_t)p.kp * 4 : 0);
-    const long grid = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
+    const long grid = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.G;      // p.M is per group
     const int idx = has_pro && p.pro.act == ISA_ACT_RELU6 ? 1 : (has_pro ? 2 : 0);
     const void* fn = idx == 1 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 1, EP>)
                    : idx == 2 ? reinterpret_cast<const void*>(&conv_gemm_tiled_kernel<WN, 2, EP>)
@@ -730,7 +747,7 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
             static const long wide_min_wgs = getenv("ISA_GEMM_TILED_WIDE_MIN") ? atol(getenv("ISA_GEMM_TILED_WIDE_MIN")) : 512;
             // 128-wide column tiles only when they still give >= 2 workgroups per CU: the second resident workgroup is
             // what keeps the MFMA pipe busy while the first one writes its next tile to LDS and waits at the barrier
-            return (p.N >= 128 && ((p.M + 127) / 128) * ((p.N + 127) / 128) >= wide_min_wgs) ? launch_tiled<2>(p, has_pro, s)
+            return (p.N >= 128 && ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.G >= wide_min_wgs) ? launch_tiled<2>(p, has_pro, s)
                                                                                                : launch_tiled<1>(p, has_pro, s);
         }
     }
@@ -738,7 +755,7 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     // low-resolution levels: few 128-pixel tiles but hundreds of output channels.  Narrower column tiles put more
     // workgroups on the chip (the re-read A operand is L2-resident at these sizes): 4096 px x 512 ch ran as 128
     // workgroups on 256 CUs.
-    const long tiles_m = (p.M + 127) / 128;
+    const long tiles_m = (p.M + 127) / 128 * p.G;
     while (nt > 1 && tiles_m * ((p.N + 32 * nt - 1) / (32 * nt)) < 512) nt /= 2;
     const int n_blk = 32 * nt;
     // weight chunk sized to <= 48 KB of LDS
@@ -751,9 +768,10 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     const size_t lds = b_bytes + (has_pro ? 2 * (size_t)p.kp * 4 : 0) + 4 * 32 * 33 * 4;
     p.ntiles = (int)((p.M + 127) / 128);
     const int gy = (p.N + n_blk - 1) / n_blk;
-    int gx = p.ntiles;
+    int gx = p.ntiles * p.G;
     const int cap = max(1, (256 * 3) / gy);          // three resident workgroups per CU (measured: 2 -> 36.5 ms, 3 -> 36.3, 4 -> 36.9)
     if (gx > cap) gx = cap;
+    gx = (int)group_grid(gx, p.G);
     dim3 grid(gx, gy);
     switch (nt) {
         case 1: return launch1<T, 1>(p, has_pro, in_mode, out_mode, grid, lds, s);
@@ -804,6 +822,14 @@ static int conv_gemm_impl(const isa_tensor* x, const isa_pro* pro, const void* w
     p.M = (long)x->n * p.mh * p.mw;
     if (p.M >= (1L << 31)) return ISA_EINVAL;
     const bool has_pro = !pro_trivial(p.pro);
+    // statistic groups matter only where per-channel statistics or constants are involved; everything else treats the
+    // batch as one problem
+    p.G = 1;
+    const int G = tensor_groups(x);
+    if (G > 1 && (stats || (pro && (pro->scale || pro->shift)))) {
+        if (in_mode != ISA_IN_1X1 || out_mode != ISA_OUT_PLAIN || ep || x->n % G || tensor_groups(y) != G) return ISA_EINVAL;
+        p.G = G; p.M /= G;
+    }
     if (!ep && in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && !has_pro && !stats && kp == 32 &&
         y->c <= 32)
         return conv3x3_tiled_launch(x, w, bias, y, accumulate, as_stream(stream));

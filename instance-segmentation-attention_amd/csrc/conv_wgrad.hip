@@ -39,6 +39,7 @@ struct WgParams {
     int groups_k;
     long nchunks;
     long ws_floats;            // host side: capacity of ws
+    int G;                     // statistic groups (plain 1x1 only): M, nchunks are per group (common.hpp)
     isa_slab_arena* sa;        // host side: deferred folds (may be NULL)
     float* ws;                 // [gridDim.x][gridDim.y][taps][TN*TK*1024 (+ TN*32 bias sums)] partial slabs
 };
@@ -66,6 +67,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
     const int n0 = gn * TN * 32, k0 = gk * TK * 32;
     float* sD = lds + wave * SLAB;
     float* sX = sD + PM * LDN;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                             // this workgroup's statistic group: rows [g*M, (g+1)*M)
+        p.x = reinterpret_cast<const T*>(p.x) + (long)gs.g * p.M * p.ldx;
+        p.dy = reinterpret_cast<const T*>(p.dy) + (long)gs.g * p.M * p.ldd;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.cin); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.cin);
+        p.pro.bscale = goff(p.pro.bscale, (long)gs.g * (p.M / ((long)p.mh * p.mw)) * p.cin);
+    }
     const T* xin = reinterpret_cast<const T*>(p.x);
     const T* din = reinterpret_cast<const T*>(p.dy);
     const bool plain = p.in_mode == ISA_IN_1X1 && p.out_mode == ISA_OUT_PLAIN;
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgParams p) {
         }
     };
 
-    const long stride = (long)gridDim.x * 4;
-    long chunk = (long)blockIdx.x * 4 + wave;
+    const long stride = (long)gs.nbx * 4;
+    long chunk = (long)gs.bx * 4 + wave;
     if (chunk < p.nchunks) fetch(chunk);
     for (; chunk < p.nchunks; chunk += stride) {
         stash();
@@ -354,6 +362,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgParams p) {
     const int n0 = gn * TN * 32, k0 = gk * TK * 32;
     char* sD = ldsb + wave * SLAB;
     char* sX = sD + PMB * SN;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                             // statistic group (see conv_wgrad_kernel)
+        p.x = reinterpret_cast<const bf16_t*>(p.x) + (long)gs.g * p.M * p.ldx;
+        p.dy = reinterpret_cast<const bf16_t*>(p.dy) + (long)gs.g * p.M * p.ldd;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.cin); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.cin);
+        p.pro.bscale = goff(p.pro.bscale, (long)gs.g * (p.M / ((long)p.mh * p.mw)) * p.cin);
+    }
     const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* din = reinterpret_cast<const bf16_t*>(p.dy);
     const bool plain = p.in_mode == ISA_IN_1X1 && p.out_mode == ISA_OUT_PLAIN;
@@ -460,8 +475,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgParams p) {
             *reinterpret_cast<bf16x8*>(sX + (v * RPK + rowk) * SK + cgk * 16) = rx[v];
     };
 
-    const long stride = (long)gridDim.x * 4;
-    long chunk = (long)blockIdx.x * 4 + wave;
+    const long stride = (long)gs.nbx * 4;
+    long chunk = (long)gs.bx * 4 + wave;
     if (chunk < nchunks) fetch(chunk);
     for (; chunk < nchunks; chunk += stride) {
         stash();
@@ -531,14 +546,14 @@ int launch_wg_bf16(WgParams& p, int groups_n, hipStream_t s) {
     const int gy = groups_n * p.groups_k;
     const long nchunks = (p.M + 31) / 32;
     const long slabf = (long)TN * TK * 1024 + TN * 32;
-    long want = (nchunks + 3) / 4;
+    long want = (nchunks + 3) / 4 * p.G;
     long cap = (256L * 2) / ((long)gy * p.taps);
     if (int rc = defer_ws(p.sa, &p.ws, &p.ws_floats)) return rc;
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
-    if (ws_cap < 1) return p.sa ? ISA_ENOMEM : ISA_EINVAL;   // workspace too small for even one slab set
+    if (ws_cap < p.G) return p.sa ? ISA_ENOMEM : ISA_EINVAL;   // workspace too small for even one slab set per group
     if (cap > ws_cap) cap = ws_cap;
     if (cap < 1) cap = 1;
-    const int gx = (int)(want < cap ? want : cap);
+    const int gx = (int)group_grid(want < cap ? want : cap, p.G);
     dim3 grid(gx, gy, p.taps);
     if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
     else if (p.pro.act == ISA_ACT_LEAKY && TN == 1 && TK == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TN, TK, ISA_ACT_LEAKY>), grid, dim3(256), lds, s, p);
@@ -557,14 +572,14 @@ int launch_wg(WgParams& p, int groups_n, hipStream_t s) {
     const size_t lds = slab > redb ? slab : redb;
     const int gy = groups_n * p.groups_k;
     const long slabf = (long)TN * TK * 1024 + TN * 32;
-    long want = (p.nchunks + 3) / 4;
+    long want = (p.nchunks + 3) / 4 * p.G;
     long cap = (256L * 2) / ((long)gy * p.taps);
     if (int rc = defer_ws(p.sa, &p.ws, &p.ws_floats)) return rc;
     const long ws_cap = p.ws_floats / (slabf * gy * p.taps);
-    if (ws_cap < 1) return p.sa ? ISA_ENOMEM : ISA_EINVAL;
+    if (ws_cap < p.G) return p.sa ? ISA_ENOMEM : ISA_EINVAL;
     if (cap > ws_cap) cap = ws_cap;
     if (cap < 1) cap = 1;
-    const int gx = (int)(want < cap ? want : cap);
+    const int gx = (int)group_grid(want < cap ? want : cap, p.G);
     dim3 grid(gx, gy, p.taps);
     if (p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
     else if (p.pro.act == ISA_ACT_NONE) hipLaunchKernelGGL((conv_wgrad_kernel<T, TN, TK, ISA_ACT_NONE>), grid, dim3(256), lds, s, p);
@@ -621,6 +636,12 @@ extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa
     } else {
         if (dy->h != x->h || dy->w != x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = in_mode == ISA_IN_3X3 ? 9 : 1; p.N = dy->c;
+    }
+    p.G = 1;
+    const int G = tensor_groups(x);
+    if (G > 1 && (p.pro.scale || p.pro.shift)) {            // only the per-channel prologue constants differ by group
+        if (in_mode != ISA_IN_1X1 || out_mode != ISA_OUT_PLAIN || x->n % G) return ISA_EINVAL;
+        p.G = G; p.M /= G;
     }
     p.nchunks = (p.M + PM - 1) / PM;
     if (in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && pro_trivial(p.pro) && !kmap &&

@@ -33,6 +33,7 @@ struct Dw2Params {
     float* stats; int accumulate;
     int tiles_x, tiles_y; long ntiles;
     float* ws; int csrc;
+    int G;                       // statistic groups: n and ntiles are per group (common.hpp)
 };
 
 // 8 storage elements kept packed in registers (4 VGPRs for bf16) until they are consumed
@@ -131,15 +132,16 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 // own L2.  Adjacent tiles share halo rows / columns, so each XCD gets ONE contiguous eighth of the tile sequence and
 // its workgroups stride inside it: the halo overlap is re-read from that XCD's L2 instead of from seven other ones.
 struct TileRange { long t0, end, step; };
-__device__ __forceinline__ TileRange tile_range(long ntiles) {
-    const int G = gridDim.x;
-    if ((G & 7) == 0 && ntiles >= 64) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+// (bx, nbx): the workgroup's index and the workgroup count inside its statistic group (GroupSel); with nbx % 8 == 0 a
+// group starts on XCD 0, so bx & 7 is still the XCD
+__device__ __forceinline__ TileRange tile_range(long ntiles, int bx, int nbx) {
+    if ((nbx & 7) == 0 && ntiles >= 64) {
+        const int xcd = bx & 7, j = bx >> 3;
         const long chunk = (ntiles + 7) / 8;
         const long end = min(ntiles, (xcd + 1) * chunk);
-        return TileRange{xcd * chunk + j, end, (long)(G >> 3)};
+        return TileRange{xcd * chunk + j, end, (long)(nbx >> 3)};
     }
-    return TileRange{(long)blockIdx.x, ntiles, (long)G};
+    return TileRange{(long)bx, ntiles, (long)nbx};
 }
 
 // Tile coordinates kept incrementally: the tile sequence of a workgroup is t0, t0 + step, ... and a 64-bit
@@ -182,6 +184,15 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
     const bool loader = DB && tid >= 256;
     const int ltid = loader ? tid - 256 : tid;        // index inside the role group
     const int c_base = blockIdx.y * CB;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                       // this workgroup's statistic group: its n images, its constants
+        const long img = (long)gs.g * p.n, pix = img * p.h * p.w_;
+        p.x = reinterpret_cast<const T*>(p.x) + pix * p.ldx;
+        p.y = reinterpret_cast<T*>(p.y) + pix * p.ldy;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.c); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.c);
+        p.pro.bscale = goff(p.pro.bscale, img * p.c);
+        p.stats = goff(p.stats, (long)gs.g * ISA_STAT_R * 2 * p.c);
+    }
     const T* wp = reinterpret_cast<const T*>(p.w);
     for (int i = tid; i < 9 * CB; i += NTHR) {
         const int tp = i / CB, cc = i - tp * CB;
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
 
     __syncthreads();                                             // weights + zeroed `red` visible
     if (loader) {
-        TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
+        TileIter ti; ti.init(tile_range(p.ntiles, gs.bx, gs.nbx), p.tiles_x, p.tiles_y);
         int buf = 0;
         if (ti.valid()) stage(ti.b, ti.ty, ti.tx, tile_base);
         __syncthreads();
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
     } else {
         float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (DB) {
-            TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
+            TileIter ti; ti.init(tile_range(p.ntiles, gs.bx, gs.nbx), p.tiles_x, p.tiles_y);
             int buf = 0;
             __syncthreads();
             for (; ti.valid(); ti.next()) {
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
                 buf ^= 1;
             }
         } else {
-            TileIter ti; ti.init(TileRange{(long)blockIdx.x, p.ntiles, (long)gridDim.x}, p.tiles_x, p.tiles_y);
+            TileIter ti; ti.init(TileRange{(long)gs.bx, p.ntiles, (long)gs.nbx}, p.tiles_x, p.tiles_y);
             for (; ti.valid(); ti.next()) {
                 stage(ti.b, ti.ty, ti.tx, tile_base);
                 __syncthreads();
@@ -378,6 +389,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int c_base = blockIdx.y * CB;
     const int cg = tid & 3, g = tid >> 2, row = g >> 3, x0 = (g & 7) * 4;
     const int c0 = c_base + cg * 8;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {
+        const long img = (long)gs.g * p.n, pix = img * p.h * p.w_;
+        p.x = reinterpret_cast<const T*>(p.x) + pix * p.ldx;
+        p.dy = reinterpret_cast<const T*>(p.dy) + pix * p.ldd;
+        p.pro.scale = goff(p.pro.scale, (long)gs.g * p.c); p.pro.shift = goff(p.pro.shift, (long)gs.g * p.c);
+        p.pro.bscale = goff(p.pro.bscale, img * p.c);
+    }
     const T* din = reinterpret_cast<const T*>(p.dy);
     float acc[9][8], db[8];
 #pragma unroll
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j] = 0.f;
-    for (long t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    for (long t = gs.bx; t < p.ntiles; t += gs.nbx) {
         const int tx = (int)(t % p.tiles_x); const long q = t / p.tiles_x;
         const int ty = (int)(q % p.tiles_y); const int b = (int)(q / p.tiles_y);
         ProRegs pr;
@@ -474,13 +493,14 @@ int launch_fwd2_inst(Dw2Params& p, dim3 grid, hipStream_t s) {
 template <typename T>
 int launch_fwd2(Dw2Params& p, bool has_pro, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
-    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
-    if (p.ntiles >= (1L << 31)) return ISA_EINVAL;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;            // p.n: images per statistic group
+    if (p.ntiles * p.G >= (1L << 31)) return ISA_EINVAL;
     const int ncb = (p.c + CB - 1) / CB;
     // persistent: bf16 = one 512-thread double-buffered workgroup per CU, f32 = three 256-thread ones
     long gx = (256L * (sizeof(T) == 2 ? 1 : 3)) / ncb;
     if (gx < 1) gx = 1;
-    if (gx > p.ntiles) gx = p.ntiles;
+    if (gx > p.ntiles * p.G) gx = p.ntiles * p.G;
+    gx = group_grid(gx, p.G);
     dim3 grid((unsigned)gx, ncb);
     if (has_pro && p.pro.act == ISA_ACT_RELU6) return launch_fwd2_inst<T, true, ISA_ACT_RELU6>(p, grid, s);
     if (has_pro) return launch_fwd2_inst<T, true, ACT_RT>(p, grid, s);
@@ -494,11 +514,12 @@ int launch_wg2(Dw2Params& p, bool has_pro, long ws_floats, isa_slab_arena* sa, h
     const int ncb = (p.c + CB - 1) / CB;
     long gx = (256L * 2) / ncb;          // 2 resident workgroups per CU
     if (gx < 1) gx = 1;
-    if (gx > p.ntiles) gx = p.ntiles;
+    if (gx > p.ntiles * p.G) gx = p.ntiles * p.G;
     if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / (10L * CB * ncb);
-    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
+    if (ws_cap < p.G) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
+    gx = group_grid(gx, p.G);
     dim3 grid((unsigned)gx, ncb);
     const size_t lds = ((size_t)HALO * PS + 10 * CB) * 4;
     if (has_pro && p.pro.act == ISA_ACT_RELU6) hipLaunchKernelGGL((dw2_wgrad_kernel<T, true, ISA_ACT_RELU6>), grid, dim3(256), lds, s, p);
@@ -529,6 +550,7 @@ struct FusedParams {
     const float *xsc, *xsh, *xmu, *xis; int xact; float* xred;
     int accumulate, tiles_x, tiles_y; long ntiles; float* ws; int csrc; float* dw;
     const void* addend; int lda;      // optional: dx += addend (gradient of the block's residual branch)
+    int G;                            // statistic groups: n and ntiles are per group (common.hpp)
 };
 
 
@@ -569,6 +591,16 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const int ltid = tid & 255;                                              // index inside the role group
     const bool loader = DB && tid >= 256;
     const int c_base = blockIdx.y * CB;
+    const GroupSel gs = group_sel(p.G);
+    if (gs.g) {                                                              // this workgroup's statistic group
+        const long pix = (long)gs.g * p.n * p.h * p.w_, gc = (long)gs.g * p.c;
+        p.g = reinterpret_cast<const T*>(p.g) + pix * p.ldg; p.y = reinterpret_cast<const T*>(p.y) + pix * p.ldy;
+        p.x = reinterpret_cast<const T*>(p.x) + pix * p.ldx; p.dx = reinterpret_cast<T*>(p.dx) + pix * p.lddx;
+        if (p.addend) p.addend = reinterpret_cast<const T*>(p.addend) + pix * p.lda;
+        p.ysc += gc; p.ysh += gc; p.ymu += gc; p.yis += gc; p.yred += gc * ISA_STAT_R * 2;
+        p.xsc = goff(p.xsc, gc); p.xsh = goff(p.xsh, gc); p.xmu = goff(p.xmu, gc); p.xis = goff(p.xis, gc);
+        p.xred = goff(p.xred, gc * ISA_STAT_R * 2);
+    }
     const int cg = ltid & 3, g4 = ltid >> 2, row = g4 >> 3, x0 = (g4 & 7) * 4;
     const int c0 = c_base + cg * 8;
     const bool cok = c0 < p.c;
@@ -587,7 +619,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         cst[4 * CB + tid] = r0 * p.ycnt_inv; cst[5 * CB + tid] = r1 * p.ycnt_inv;
         cst[6 * CB + tid] = (XMODE && p.xsc) ? p.xsc[c] : 1.f; cst[7 * CB + tid] = (XMODE && p.xsh) ? p.xsh[c] : 0.f;
         cst[8 * CB + tid] = (XMODE && p.xmu) ? p.xmu[c] : 0.f; cst[9 * CB + tid] = (XMODE && p.xis) ? p.xis[c] : 1.f;
-        if (blockIdx.x == 0 && c_base + tid < p.c) {             // BN(y) parameter gradients: dbeta = sum g', dgamma = sum g'*yhat
+        if (gs.bx == 0 && c_base + tid < p.c) {                  // BN(y) parameter gradients: dbeta = sum g', dgamma = sum g'*yhat (per group)
             if (p.ydgamma) atomicAdd(p.ydgamma + c, r1);
             if (p.ydbeta) atomicAdd(p.ydbeta + c, r0);
         }
@@ -823,7 +855,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         StageK K;
         ld8(cst + 0 * CB + cg * 8, K.sc); ld8(cst + 1 * CB + cg * 8, K.sh); ld8(cst + 2 * CB + cg * 8, K.mu);
         ld8(cst + 3 * CB + cg * 8, K.is); ld8(cst + 4 * CB + cg * 8, K.k0); ld8(cst + 5 * CB + cg * 8, K.k1);
-        TileIter tn; tn.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);     // the tile whose loads are in flight
+        TileIter tn; tn.init(tile_range(p.ntiles, gs.bx, gs.nbx), p.tiles_x, p.tiles_y);     // the tile whose loads are in flight
         raw8<T> gv[NIT], yv[NIT], xv[NIT];
         Geo gs, gn;
         bool have = tn.valid();
@@ -862,7 +894,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
         if constexpr (DB) {
-            TileIter ti; ti.init(tile_range(p.ntiles), p.tiles_x, p.tiles_y);
+            TileIter ti; ti.init(tile_range(p.ntiles, gs.bx, gs.nbx), p.tiles_x, p.tiles_y);
             int buf = 0;
             lds_barrier();                                       // first tile staged
             for (; ti.valid(); ti.next()) {
@@ -871,7 +903,7 @@ __global__ __launch_bounds__(DB ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 buf ^= 1;
             }
         } else {
-            TileIter ti; ti.init(TileRange{(long)blockIdx.x, p.ntiles, (long)gridDim.x}, p.tiles_x, p.tiles_y);
+            TileIter ti; ti.init(TileRange{(long)gs.bx, p.ntiles, (long)gs.nbx}, p.tiles_x, p.tiles_y);
             for (; ti.valid(); ti.next()) {
                 stage(ti.b, ti.ty, ti.tx, xt_base, dt_base);
                 __syncthreads();
@@ -945,16 +977,17 @@ int launch_fused_inst(FusedParams& p, dim3 grid, hipStream_t s) {
 template <typename T>
 int launch_fused(FusedParams& p, int xmode, long ws_floats, isa_slab_arena* sa, hipStream_t s) {
     p.tiles_x = (p.w_ + TW - 1) / TW; p.tiles_y = (p.h + TH - 1) / TH;
-    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;
+    p.ntiles = (long)p.n * p.tiles_x * p.tiles_y;              // p.n: images per statistic group
     const int ncb = (p.c + CB - 1) / CB;
     const int per_cu = 1;                                        // LDS: 156 KB (bf16, double-buffered) / 100 KB (f32)
     long gx = (256L * per_cu) / ncb;
     if (gx < 1) gx = 1;
-    if (gx > p.ntiles) gx = p.ntiles;
+    if (gx > p.ntiles * p.G) gx = p.ntiles * p.G;
     if (int rc = defer_ws(sa, &p.ws, &ws_floats)) return rc;
     const long ws_cap = ws_floats / (10L * CB * ncb);
-    if (ws_cap < 1) return sa ? ISA_ENOMEM : ISA_EINVAL;
+    if (ws_cap < p.G) return sa ? ISA_ENOMEM : ISA_EINVAL;
     if (gx > ws_cap) gx = ws_cap;
+    gx = group_grid(gx, p.G);
     dim3 grid((unsigned)gx, ncb);
     int rc;
     const bool y6 = p.yact == ISA_ACT_RELU6;
@@ -978,6 +1011,12 @@ int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const fl
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldy = y->ld; p.wld = ((x->c + 7) / 8) * 8;
     p.pro = make_pro(pro); p.stats = stats; p.accumulate = accumulate;
     const bool has_pro = !pro_trivial(p.pro);
+    p.G = 1;
+    const int G = tensor_groups(x);
+    if (G > 1 && (stats || p.pro.scale || p.pro.shift)) {
+        if (x->n % G || tensor_groups(y) != G) return ISA_EINVAL;
+        p.G = G; p.n = x->n / G;
+    }
     if (x->dtype == ISA_BF16) return launch_fwd2<bf16_t>(p, has_pro, as_stream(stream));
     return launch_fwd2<float>(p, has_pro, as_stream(stream));
 }
@@ -989,6 +1028,12 @@ int dw2_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy, flo
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldd = dy->ld;
     p.pro = make_pro(pro); p.ws = ws; p.csrc = (csrc > 0 && csrc < x->c) ? csrc : x->c;
     const bool has_pro = !pro_trivial(p.pro);
+    p.G = 1;
+    const int G = tensor_groups(x);
+    if (G > 1 && (p.pro.scale || p.pro.shift)) {
+        if (x->n % G) return ISA_EINVAL;
+        p.G = G; p.n = x->n / G;
+    }
     if (x->dtype == ISA_BF16) return launch_wg2<bf16_t>(p, has_pro, ws_floats, defer, as_stream(stream));
     return launch_wg2<float>(p, has_pro, ws_floats, defer, as_stream(stream));
 }
@@ -1025,6 +1070,9 @@ extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* 
         if (!pro_trivial(make_pro(xpro)) || xbn) return ISA_EINVAL;      // only for a plain-tensor x
     }
     p.csrc = (csrc > 0 && csrc < g->c) ? csrc : g->c;
+    p.G = tensor_groups(g);                                          // BN(y) constants and sums are per statistic group
+    if (g->n % p.G) return ISA_EINVAL;
+    p.n = g->n / p.G;
     int xmode = 0;
     if (!pro_trivial(xp) || xbn) xmode = (xbn && xp.act == ISA_ACT_RELU6) ? 1 : 2;
     if (g->dtype == ISA_BF16) return launch_fused<bf16_t>(p, xmode, ws_floats, defer, as_stream(stream));

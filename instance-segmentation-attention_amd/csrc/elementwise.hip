@@ -59,28 +59,41 @@ __global__ void pack_kernel(const isa_pack_entry* tab, const int32_t* kmap, cons
 // ------------------------------------------------------------------------------------------
 // BatchNorm finalize
 // ------------------------------------------------------------------------------------------
+// groups > 1: stats [G][R][2c] -> scale/shift/mean/invstd [G][c]; the running statistics take the G updates in group
+// order (the reference runs the groups - its decoder iterations - one after the other through the same module);
+// repeat > 1: the same update applied `repeat` times (a layer whose identical forward the reference runs `repeat` times).
 __global__ void bn_finalize_kernel(const float* stats, float count, const float* gamma,
                                    const float* beta, float* rm, float* rv, float momentum, float eps,
-                                   float* scale, float* shift, float* mean_o, float* invstd_o, int c) {
+                                   float* scale, float* shift, float* mean_o, float* invstd_o, int c, int groups, int repeat) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
-        float mean, var;
-        if (stats) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < ISA_STAT_R; ++r) { s1 += stats[r * 2 * c + i]; s2 += stats[r * 2 * c + c + i]; }
-            mean = s1 / count;
-            var = fmaxf(s2 / count - mean * mean, 0.f);
-            if (rm) rm[i] = (1.f - momentum) * rm[i] + momentum * mean;
-            if (rv) rv[i] = (1.f - momentum) * rv[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
-        } else {
-            mean = rm[i]; var = rv[i];
-        }
-        const float inv = 1.0f / sqrtf(var + eps);
         const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
-        scale[i] = g * inv;
-        shift[i] = b - mean * g * inv;
-        if (mean_o) mean_o[i] = mean;
-        if (invstd_o) invstd_o[i] = inv;
+        float rmi = rm ? rm[i] : 0.f, rvi = rv ? rv[i] : 0.f;
+        for (int gi = 0; gi < groups; ++gi) {
+            float mean, var;
+            if (stats) {
+                const float* st = stats + (long)gi * ISA_STAT_R * 2 * c;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < ISA_STAT_R; ++r) { s1 += st[r * 2 * c + i]; s2 += st[r * 2 * c + c + i]; }
+                mean = s1 / count;
+                var = fmaxf(s2 / count - mean * mean, 0.f);
+                for (int k = 0; k < repeat; ++k) {
+                    rmi = (1.f - momentum) * rmi + momentum * mean;
+                    rvi = (1.f - momentum) * rvi + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+                }
+            } else {
+                mean = rmi; var = rvi;
+            }
+            const float inv = 1.0f / sqrtf(var + eps);
+            scale[gi * c + i] = g * inv;
+            shift[gi * c + i] = b - mean * g * inv;
+            if (mean_o) mean_o[gi * c + i] = mean;
+            if (invstd_o) invstd_o[gi * c + i] = inv;
+        }
+        if (stats) {
+            if (rm) rm[i] = rmi;
+            if (rv) rv[i] = rvi;
+        }
     }
 }
 
@@ -114,6 +127,7 @@ struct BnBwdParams {
     float* out_red; float* dgamma; float* dbeta;
     float inv_count; int act, train;
     long pixels; int cg;
+    int groups;                  // statistic groups (blockIdx.z): pixels / wk.pixels are per group
 };
 
 // Division-free walk over (pixel, 8-channel group): a workgroup is laid out as
@@ -137,6 +151,16 @@ template <typename T, bool APPLY, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
     extern __shared__ float red[];              // [2*C]: reduce pass partial sums / apply pass folded sums
     const int C = p.y.c;
+    if (p.groups > 1 && blockIdx.z) {           // this workgroup's statistic group: its images and its constants
+        const long g = blockIdx.z, gp = g * wk.pixels;
+        p.dt.data = reinterpret_cast<T*>(p.dt.data) + gp * p.dt.ld;
+        p.y.data = reinterpret_cast<T*>(p.y.data) + gp * p.y.ld;
+        if (APPLY) p.dy.data = reinterpret_cast<T*>(p.dy.data) + gp * p.dy.ld;
+        p.scale = goff(p.scale, g * C); p.shift = goff(p.shift, g * C); p.mean = goff(p.mean, g * C);
+        p.invstd = goff(p.invstd, g * C);
+        p.bscale = goff(p.bscale, g * (wk.pixels / ((long)p.y.h * p.y.w)) * C);
+        p.red = goff(p.red, g * ISA_STAT_R * 2 * C); p.out_red = goff(p.out_red, g * ISA_STAT_R * 2 * C);
+    }
     if (!APPLY) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
@@ -223,10 +247,25 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
 }
 
 // out = (pro(x) (+ res) (+ res2)) * oscale[b,c]
-struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; };
+// groups (blockIdx.z): pixels / wk.pixels are per group.  bcast: x (and res) hold ONE group of images that every output
+// group reads (an identical sub-network evaluated once for all decoder iterations; only the per-image oscale differs).
+struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; int groups, bcast; };
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) {
     const int C = p.x.c;
+    if (p.groups > 1 && blockIdx.z) {
+        const long g = blockIdx.z, gp = g * wk.pixels;
+        const long gimg = g * (wk.pixels / ((long)p.x.h * p.x.w)) * C;
+        p.out.data = reinterpret_cast<T*>(p.out.data) + gp * p.out.ld;
+        if (p.has_res2) p.res2.data = reinterpret_cast<T*>(p.res2.data) + gp * p.res2.ld;
+        p.oscale = goff(p.oscale, gimg);
+        if (!p.bcast) {
+            p.x.data = reinterpret_cast<T*>(p.x.data) + gp * p.x.ld;
+            if (p.has_res) p.res.data = reinterpret_cast<T*>(p.res.data) + gp * p.res.ld;
+            p.pro.scale = goff(p.pro.scale, g * C); p.pro.shift = goff(p.pro.shift, g * C);
+            p.pro.bscale = goff(p.pro.bscale, gimg);
+        }
+    }
     const int ppb = 256 >> wk.sh;
     const int psub = threadIdx.x >> wk.sh;
     const unsigned hw = (unsigned)p.x.h * (unsigned)p.x.w;
@@ -548,10 +587,13 @@ extern "C" int isa_pack_weights(const isa_pack_entry* table_dev, int32_t n_entri
 extern "C" int isa_bn_finalize(const float* stats, float count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, float* scale, float* shift,
-                               float* mean, float* invstd, int32_t c, void* stream) {
+                               float* mean, float* invstd, int32_t c, int32_t groups, int32_t repeat, void* stream) {
     if (c <= 0 || !scale || !shift || (!stats && (!running_mean || !running_var))) return ISA_EINVAL;
+    if (groups < 1) groups = 1;
+    if (repeat < 1) repeat = 1;
+    if (!stats && groups != 1) return ISA_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), stats, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, c);
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, c, groups, repeat);
     return launch_status();
 }
 
@@ -574,8 +616,11 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     if (!tensor_ok(dt, 8) || !tensor_ok(y, 8) || !same_shape(dt, y)) return ISA_EINVAL;
     p.dt = mkview(dt); p.y = mkview(y);
     if (apply) { if (!tensor_ok(dy, 8) || !same_shape(dy, y)) return ISA_EINVAL; p.dy = mkview(dy); }
-    p.pixels = (long)y->n * y->h * y->w; p.cg = (y->c + 7) / 8;
-    if (p.pixels >= (1L << 32)) return ISA_EINVAL;
+    const int G = tensor_groups(y);
+    if (y->n % G) return ISA_EINVAL;
+    p.groups = G;
+    p.pixels = (long)(y->n / G) * y->h * y->w; p.cg = (y->c + 7) / 8;     // per group
+    if (p.pixels * G >= (1L << 32)) return ISA_EINVAL;
     // wide tensors (> 128 channels): blockIdx.y owns a 32-channel chunk, so a workgroup's O(C) prologue /
     // epilogue (replica fold, per-channel atomics) covers 32 channels instead of C, and the pixel dimension can
     // be split across enough workgroups to fill the chip (16x16x16 px x 1024 ch used to run as 128 workgroups
@@ -603,8 +648,8 @@ static int bn_bwd_common(const isa_tensor* dt, const isa_tensor* y, const isa_te
     const size_t lds = 2 * (size_t)y->c * 4;
 #define BN_BWD_LAUNCH(AP, ACTV) \
     DISPATCH_T(y->dtype, \
-        hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid, gy), dim3(256), lds, as_stream(stream), p, wk), \
-        hipLaunchKernelGGL((bn_bwd_kernel<float, AP, ACTV>), dim3(grid, gy), dim3(256), lds, as_stream(stream), p, wk))
+        hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, AP, ACTV>), dim3(grid, gy, G), dim3(256), lds, as_stream(stream), p, wk), \
+        hipLaunchKernelGGL((bn_bwd_kernel<float, AP, ACTV>), dim3(grid, gy, G), dim3(256), lds, as_stream(stream), p, wk))
     if (apply) {
         if (p.act == ISA_ACT_RELU6) BN_BWD_LAUNCH(true, ISA_ACT_RELU6);
         else if (p.act == ISA_ACT_NONE) BN_BWD_LAUNCH(true, ISA_ACT_NONE);
@@ -644,26 +689,34 @@ extern "C" int isa_bn_bwd_apply(const isa_tensor* dt, const isa_tensor* y, const
 extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const isa_tensor* res,
                                   const isa_tensor* res2, const float* oscale,
                                   const isa_tensor* out, void* stream) {
-    if (!tensor_ok(x, 8) || !tensor_ok(out, 8) || !same_shape(x, out)) return ISA_EINVAL;
+    if (!tensor_ok(x, 8) || !tensor_ok(out, 8)) return ISA_EINVAL;
+    // broadcast form: x (and res) hold n images, out G*n - every output group is (pro(x) + res (+ res2[g])) * oscale[g]
+    const int G = tensor_groups(out);
+    const bool bcast = G > 1 && out->n == G * x->n && tensor_groups(x) == 1;
+    if (bcast) {
+        if (x->h != out->h || x->w != out->w || x->c != out->c || x->dtype != out->dtype) return ISA_EINVAL;
+    } else if (!same_shape(x, out)) return ISA_EINVAL;
+    if (out->n % G) return ISA_EINVAL;
     if (res && (!tensor_ok(res, 8) || !same_shape(res, x))) return ISA_EINVAL;
-    if (res2 && (!tensor_ok(res2, 8) || !same_shape(res2, x))) return ISA_EINVAL;
+    if (res2 && (!tensor_ok(res2, 8) || !same_shape(res2, out))) return ISA_EINVAL;
     MatParams p{};
     p.x = mkview(x); p.out = mkview(out); p.pro = make_pro(pro); p.has_res = res != nullptr;
     p.has_res2 = res2 != nullptr; p.oscale = oscale;
     if (res) p.res = mkview(res);
     if (res2) p.res2 = mkview(res2);
-    p.pixels = (long)x->n * x->h * x->w; p.cg = (x->c + 7) / 8;
-    if (p.pixels >= (1L << 32)) return ISA_EINVAL;
+    p.groups = G; p.bcast = bcast;
+    p.pixels = (long)(out->n / G) * x->h * x->w; p.cg = (x->c + 7) / 8;       // per group
+    if (p.pixels * G >= (1L << 32)) return ISA_EINVAL;
     const Walk wk = mkwalk(x->c, p.pixels);
-    const int grid = walk_grid(wk);
+    const dim3 grid(walk_grid(wk), 1, G);
     if (p.pro.act == ISA_ACT_NONE)
         DISPATCH_T(x->dtype,
-            hipLaunchKernelGGL((materialize_kernel<bf16_t, ISA_ACT_NONE>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
-            hipLaunchKernelGGL((materialize_kernel<float, ISA_ACT_NONE>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
+            hipLaunchKernelGGL((materialize_kernel<bf16_t, ISA_ACT_NONE>), grid, dim3(256), 0, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((materialize_kernel<float, ISA_ACT_NONE>), grid, dim3(256), 0, as_stream(stream), p, wk));
     else
         DISPATCH_T(x->dtype,
-            hipLaunchKernelGGL((materialize_kernel<bf16_t, ACT_RT>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk),
-            hipLaunchKernelGGL((materialize_kernel<float, ACT_RT>), dim3(grid), dim3(256), 0, as_stream(stream), p, wk));
+            hipLaunchKernelGGL((materialize_kernel<bf16_t, ACT_RT>), grid, dim3(256), 0, as_stream(stream), p, wk),
+            hipLaunchKernelGGL((materialize_kernel<float, ACT_RT>), grid, dim3(256), 0, as_stream(stream), p, wk));
     return launch_status();
 }
 

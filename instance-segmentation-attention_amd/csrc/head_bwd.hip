@@ -29,7 +29,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 //   dL/dp1 = c_t*t + c_1 + c_focal*dfocal/dp1 ;  dL/dp0 = c_focal*dfocal/dp0 ;  dL/dl1 += c_ce*(p1-t)
 // ---------------------------------------------------------------------------------------------
 struct HeadLossParams {
-    const float* sums; const float* alpha; const int32_t* s_t; long L; int B;
+    const float* sums; const float* alpha; const int32_t* s_t; long L; int B, iters;
     float w[5]; float ce_weight, lambda_l, lambda_r, inv_iter;
     float* baseline; int training;
     float* coef; float* adv; float* scal;
@@ -38,52 +38,59 @@ __global__ __launch_bounds__(1024) void head_loss_kernel(HeadLossParams p) {
     __shared__ float sh[16];
     const int b = threadIdx.x;
     const bool on = b < p.B;
-    float loss_pred = 0.f, d4 = 0.f, d4sq = 0.f, ce_sum = 0.f, cnt4 = 0.f;
-    if (on) {
-        for (int l = 0; l < 5; ++l) {
-            const float* s = p.sums + ((long)l * p.B + b) * 8;
-            const float A = s[0], S = s[1], T = s[2], F = s[3], cnt = s[6];
-            const float den = S + T + 1.f;
-            const float D = 1.f - (2.f * A + 1.f) / den;
-            loss_pred += p.w[l] * (p.ce_weight * F / cnt + D);
-            const float g = p.inv_iter / (float)p.B * p.lambda_l * p.w[l];
-            float* c = p.coef + ((long)l * p.B + b) * 4;
-            c[0] = p.training ? g * (-2.f / den) : 0.f;
-            c[1] = p.training ? g * (2.f * A + 1.f) / (den * den) : 0.f;
-            c[2] = p.training ? g * p.ce_weight / cnt : 0.f;
-            c[3] = 0.f;
-            if (l == 4) {
-                d4 = D; ce_sum = s[4]; cnt4 = cnt;
-                d4sq = 1.f - (2.f * A + 1.f) / (s[5] + T + 1.f);       // dice with time=2 (eval branch)
+    const int rows = p.iters * p.B;                         // images per level in sums / coef: [level][iteration][image]
+    float base = p.baseline[0];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    // the iterations in order: the EMA baseline of iteration i is what iteration i + 1 starts from (attenet2.py:266)
+    for (int it = 0; it < p.iters; ++it) {
+        const int row = it * p.B + b;
+        float loss_pred = 0.f, d4 = 0.f, d4sq = 0.f, ce_sum = 0.f, cnt4 = 0.f;
+        if (on) {
+            for (int l = 0; l < 5; ++l) {
+                const float* s = p.sums + ((long)l * rows + row) * 8;
+                const float A = s[0], S = s[1], T = s[2], F = s[3], cnt = s[6];
+                const float den = S + T + 1.f;
+                const float D = 1.f - (2.f * A + 1.f) / den;
+                loss_pred += p.w[l] * (p.ce_weight * F / cnt + D);
+                const float g = p.inv_iter / (float)p.B * p.lambda_l * p.w[l];
+                float* c = p.coef + ((long)l * rows + row) * 4;
+                c[0] = p.training ? g * (-2.f / den) : 0.f;
+                c[1] = p.training ? g * (2.f * A + 1.f) / (den * den) : 0.f;
+                c[2] = p.training ? g * p.ce_weight / cnt : 0.f;
+                c[3] = 0.f;
+                if (l == 4) {
+                    d4 = D; ce_sum = s[4]; cnt4 = cnt;
+                    d4sq = 1.f - (2.f * A + 1.f) / (s[5] + T + 1.f);       // dice with time=2 (eval branch)
+                }
             }
         }
-    }
-    const float lp = -d4;                                   // log_p_y = -eval_dice
-    const float mean_lp = block_sum(on ? lp : 0.f, sh) / (float)p.B;
-    const float ce = block_sum(on ? ce_sum : 0.f, sh) / block_sum(on ? cnt4 : 0.f, sh);
-    const float dsum = block_sum(on ? d4 : 0.f, sh);
-    float base = p.baseline[0];
-    if (p.training) base = 0.9f * base + 0.1f * mean_lp;
-    float per_img = 0.f;
-    if (on && p.training) {
-        const float picked = p.alpha[(long)b * p.L + p.s_t[b]];
-        const float loss_r = -(lp - base) * logf(picked);
-        per_img = p.lambda_l * loss_pred + p.lambda_r * loss_r;
-        p.adv[b] = p.inv_iter / (float)p.B * p.lambda_r * (lp - base);
-    }
-    const float tot = block_sum(per_img, sh);
-    const float d2sum = block_sum(on ? d4sq : 0.f, sh);
-    if (threadIdx.x == 0) {
-        if (p.training) {
-            p.baseline[0] = base;
-            p.scal[0] += p.inv_iter * tot / (float)p.B;                 // ins_cost without the NaN entropy term
-            p.scal[1] += p.inv_iter * (ce + dsum);                     // criterion
-        } else {
-            p.scal[0] += p.inv_iter * d2sum / (float)p.B;
-            p.scal[1] += p.inv_iter * (ce + dsum / (float)p.B);
+        const float lp = -d4;                                   // log_p_y = -eval_dice
+        const float mean_lp = block_sum(on ? lp : 0.f, sh) / (float)p.B;
+        const float ce = block_sum(on ? ce_sum : 0.f, sh) / block_sum(on ? cnt4 : 0.f, sh);
+        const float dsum = block_sum(on ? d4 : 0.f, sh);
+        if (p.training) base = 0.9f * base + 0.1f * mean_lp;
+        float per_img = 0.f;
+        if (on && p.training) {
+            const float picked = p.alpha[(long)row * p.L + p.s_t[row]];
+            const float loss_r = -(lp - base) * logf(picked);
+            per_img = p.lambda_l * loss_pred + p.lambda_r * loss_r;
+            p.adv[row] = p.inv_iter / (float)p.B * p.lambda_r * (lp - base);
         }
-        p.scal[2] += p.inv_iter * ce;
-        p.scal[3] += p.inv_iter * dsum / (float)p.B;
+        const float tot = block_sum(per_img, sh);
+        const float d2sum = block_sum(on ? d4sq : 0.f, sh);
+        if (p.training) {
+            acc0 += p.inv_iter * tot / (float)p.B;                      // ins_cost without the NaN entropy term
+            acc1 += p.inv_iter * (ce + dsum);                           // criterion
+        } else {
+            acc0 += p.inv_iter * d2sum / (float)p.B;
+            acc1 += p.inv_iter * (ce + dsum / (float)p.B);
+        }
+        acc2 += p.inv_iter * ce;
+        acc3 += p.inv_iter * dsum / (float)p.B;
+    }
+    if (threadIdx.x == 0) {
+        if (p.training) p.baseline[0] = base;
+        p.scal[0] += acc0; p.scal[1] += acc1; p.scal[2] += acc2; p.scal[3] += acc3;
     }
 }
 
@@ -137,14 +144,19 @@ __global__ __launch_bounds__(256) void mask_loss_grad_kernel(View pred, const fl
 // ---------------------------------------------------------------------------------------------
 // REINFORCE path: d merge[b,p] += adv[b] * (alpha[b,p] - [p == s_t[b]]) on the instance's pixels
 // ---------------------------------------------------------------------------------------------
+// rows [it*nsrc + image] of `iters` decoder iterations; a workgroup owns pixels of ONE image and walks its iterations, so
+// the read-modify-write of dmerge needs no atomics
 __global__ __launch_bounds__(256) void ins_softmax_bwd_kernel(const float* alpha, const int64_t* ins, const int32_t* idx,
                                                               const int32_t* s_t, const float* adv, int nobj, long L,
-                                                              float* dmerge) {
-    const int b = blockIdx.y;
-    const int64_t* plane = ins + ((long)b * nobj + idx[b]) * L;
-    const float a = adv[b]; const int s = s_t[b];
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < L; p += (long)gridDim.x * 256)
-        if (plane[p] != 0) dmerge[(long)b * L + p] += a * (alpha[(long)b * L + p] - (p == s ? 1.f : 0.f));
+                                                              float* dmerge, int nsrc, int iters) {
+    const int bi = blockIdx.y;
+    for (int it = 0; it < iters; ++it) {
+        const int b = it * nsrc + bi;
+        const int64_t* plane = ins + ((long)bi * nobj + idx[b]) * L;
+        const float a = adv[b]; const int s = s_t[b];
+        for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < L; p += (long)gridDim.x * 256)
+            if (plane[p] != 0) dmerge[(long)bi * L + p] += a * (alpha[(long)b * L + p] - (p == s ? 1.f : 0.f));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -597,9 +609,11 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(View dxa, const float
 
 // dst (+)= src * s[b,c]
 template <typename T>
-__global__ __launch_bounds__(256) void scale_bc_kernel(View src, const float* s, View dst, int accumulate) {
+// fold > 1: src holds fold * dst.n images; dst[b] (+)= sum_g src[g*n + b] * s[g*n + b] (the gradient of a tensor that was
+// broadcast to `fold` statistic groups with a per-image scale each)
+__global__ __launch_bounds__(256) void scale_bc_kernel(View src, const float* s, View dst, int accumulate, int fold) {
     const int C = src.c, cg = (C + 7) / 8;
-    const long pixels = (long)src.n * src.h * src.w, hw = (long)src.h * src.w;
+    const long pixels = (long)dst.n * src.h * src.w, hw = (long)src.h * src.w;
     for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < pixels * cg; item += (long)gridDim.x * 256) {
         const int c0 = (int)(item % cg) * 8; const long pix = item / cg; const long b = pix / hw;
         const int nv = min(8, C - c0);
@@ -607,6 +621,12 @@ __global__ __launch_bounds__(256) void scale_bc_kernel(View src, const float* s,
         load8g<T>(reinterpret_cast<const T*>(src.data) + pix * src.ld + c0, d, nv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] *= s[b * C + min(c0 + j, C - 1)];
+        for (int g = 1; g < fold; ++g) {
+            float e[8];
+            load8g<T>(reinterpret_cast<const T*>(src.data) + (g * pixels + pix) * src.ld + c0, e, nv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = fmaf(e[j], s[(g * dst.n + b) * C + min(c0 + j, C - 1)], d[j]);
+        }
         T* o = reinterpret_cast<T*>(dst.data) + pix * dst.ld + c0;
         if (accumulate) {
             float old[8]; load8g<T>(o, old, nv);
@@ -652,10 +672,11 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g,
 
 extern "C" int isa_head_loss(const float* sums, const float* alpha, const int32_t* s_t, int64_t L, int32_t B,
                              const float* level_w, float ce_weight, float lambda_l, float lambda_r, float inv_iter,
-                             float* baseline, int32_t training, float* coef, float* adv, float* scal, void* stream) {
+                             float* baseline, int32_t training, float* coef, float* adv, float* scal, int32_t iters, void* stream) {
     if (!sums || !alpha || !s_t || !level_w || !baseline || !coef || !adv || !scal || B <= 0 || B > 1024) return ISA_EINVAL;
+    if (iters < 1) iters = 1;
     HeadLossParams p{};
-    p.sums = sums; p.alpha = alpha; p.s_t = s_t; p.L = L; p.B = B;
+    p.sums = sums; p.alpha = alpha; p.s_t = s_t; p.L = L; p.B = B; p.iters = iters;
     for (int i = 0; i < 5; ++i) p.w[i] = level_w[i];
     p.ce_weight = ce_weight; p.lambda_l = lambda_l; p.lambda_r = lambda_r; p.inv_iter = inv_iter;
     p.baseline = baseline; p.training = training; p.coef = coef; p.adv = adv; p.scal = scal;
@@ -681,10 +702,13 @@ extern "C" int isa_mask_loss_grad(const isa_tensor* pred, const float* target, c
 }
 
 extern "C" int isa_ins_softmax_bwd(const float* alpha, const int64_t* ins, const int32_t* idx, const int32_t* s_t,
-                                   const float* adv, int32_t n, int32_t nobj, int64_t L, float* dmerge, void* stream) {
-    if (!alpha || !ins || !idx || !s_t || !adv || !dmerge) return ISA_EINVAL;
-    dim3 grid(grid_cap(cdiv(L, 256), 128), n);
-    hipLaunchKernelGGL(ins_softmax_bwd_kernel, grid, dim3(256), 0, as_stream(stream), alpha, ins, idx, s_t, adv, nobj, (long)L, dmerge);
+                                   const float* adv, int32_t n, int32_t nobj, int64_t L, float* dmerge, int32_t nsrc, void* stream) {
+    if (!alpha || !ins || !idx || !s_t || !adv || !dmerge || n <= 0) return ISA_EINVAL;
+    if (nsrc <= 0) nsrc = n;
+    if (n % nsrc) return ISA_EINVAL;
+    dim3 grid(grid_cap(cdiv(L, 256), 128), nsrc);
+    hipLaunchKernelGGL(ins_softmax_bwd_kernel, grid, dim3(256), 0, as_stream(stream), alpha, ins, idx, s_t, adv, nobj, (long)L, dmerge,
+                       nsrc, n / nsrc);
     return launch_status();
 }
 
@@ -783,11 +807,13 @@ extern "C" int isa_se_bwd(const isa_tensor* dxa, const isa_tensor* x, const floa
 
 extern "C" int isa_scale_bc(const isa_tensor* src, const float* s_bc, const isa_tensor* dst, int32_t accumulate, void* stream) {
     if (!tensor_ok(src, 8) || !tensor_ok(dst, 8) || src->c != dst->c || src->dtype != dst->dtype || !s_bc) return ISA_EINVAL;
-    const long items = (long)src->n * src->h * src->w * ((src->c + 7) / 8);
+    if (src->h != dst->h || src->w != dst->w || dst->n <= 0 || src->n % dst->n) return ISA_EINVAL;
+    const int fold = src->n / dst->n;                  // 1: plain; G: sum over the G groups of src
+    const long items = (long)dst->n * src->h * src->w * ((src->c + 7) / 8);
     const int grid = grid_cap(cdiv(items, 256));
     DISPATCH_T(src->dtype,
-        hipLaunchKernelGGL(scale_bc_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(src), s_bc, mkview(dst), accumulate),
-        hipLaunchKernelGGL(scale_bc_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(src), s_bc, mkview(dst), accumulate));
+        hipLaunchKernelGGL(scale_bc_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(src), s_bc, mkview(dst), accumulate, fold),
+        hipLaunchKernelGGL(scale_bc_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), mkview(src), s_bc, mkview(dst), accumulate, fold));
     return launch_status();
 }
 

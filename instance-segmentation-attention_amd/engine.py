@@ -39,10 +39,12 @@ class Pro:
 
 
 class Act:
-    """A channel slice [c0, c0+c) of an NHWC buffer [n,h,w,ld]."""
-    __slots__ = ("buf", "c0", "c", "pro", "_c", "needs_grad", "bn")
+    """A channel slice [c0, c0+c) of an NHWC buffer [n,h,w,ld].  groups > 1: the n images are `groups` consecutive
+    statistic groups (decoder iterations batched into one pass) with separate BatchNorm statistics - every per-channel
+    array that travels with the tensor (prologue scale/shift, statistics, BN-backward constants) is [groups][c]."""
+    __slots__ = ("buf", "c0", "c", "pro", "_c", "needs_grad", "bn", "groups")
 
-    def __init__(self, buf: torch.Tensor, c0=0, c=None, pro: Optional[Pro] = None, needs_grad=True):
+    def __init__(self, buf: torch.Tensor, c0=0, c=None, pro: Optional[Pro] = None, needs_grad=True, groups=1):
         assert buf.dim() == 4 and buf.is_contiguous()
         self.buf, self.c0 = buf, c0
         self.c = buf.shape[3] - c0 if c is None else c
@@ -50,9 +52,11 @@ class Act:
         self.pro = pro
         self.needs_grad = needs_grad
         self.bn = None
+        self.groups = groups
         n, h, w, ld = buf.shape
+        assert n % groups == 0
         self._c = L.IsaTensor(buf.data_ptr() + c0 * buf.element_size(), n, h, w, self.c, ld,
-                              L.dtype_code(buf.dtype))
+                              L.dtype_code(buf.dtype), groups)
 
     n = property(lambda s: s.buf.shape[0])
     h = property(lambda s: s.buf.shape[1])
@@ -66,11 +70,15 @@ class Act:
         return self.pro.c() if self.pro is not None else None
 
     def slice(self, c0, c, pro=None):
-        return Act(self.buf, self.c0 + c0, c, pro, self.needs_grad)
+        return Act(self.buf, self.c0 + c0, c, pro, self.needs_grad, self.groups)
 
     def with_pro(self, pro):
-        a = Act(self.buf, self.c0, self.c, pro, self.needs_grad)
+        a = Act(self.buf, self.c0, self.c, pro, self.needs_grad, self.groups)
         return a
+
+    def images(self, b0, nb):
+        """Images [b0, b0+nb) as a view of their own (one statistic group of a batched tensor; tests / captures)."""
+        return Act(self.buf[b0:b0 + nb], self.c0, self.c, None, self.needs_grad, 1)
 
     def nchw(self) -> torch.Tensor:
         """Materialised copy as NCHW float32 (tests / outputs only; applies no prologue)."""
@@ -353,7 +361,7 @@ class GradBook:
             g = self.eng.arena.alloc(a.buf.shape, a.buf.dtype)
             self.bufs[key] = g
             self.written[key] = []
-        return Act(g, a.c0, a.c)
+        return Act(g, a.c0, a.c, groups=a.groups)
 
     def _covered(self, key, lo, hi):
         """Return (fully_written, fully_unwritten, missing ranges) for [lo,hi)."""
@@ -499,6 +507,7 @@ class Engine:
         self.fold_stats = (0, 0)       # (folds, arena floats) of the last backward pass
         self._deferring = False
         self.defer_fold = os.environ.get("ISA_DEFER_FOLD", "1") != "0"    # 0: immediate folds (A/B, single stream only)
+        self.bn_repeat = 1             # see repeated()
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool, key=None):
@@ -584,17 +593,19 @@ class Engine:
         L.check(self.lib.isa_bn_running_update(arr, len(q), self.BN_MOMENTUM, self.st()), "isa_bn_running_update")
         self.bn_running_queue = []
 
-    def _finalize_train(self, stats, count, pre, c, scale, shift, mean, invstd):
+    def _finalize_train(self, stats, count, pre, c, scale, shift, mean, invstd, groups=1):
         P = self.params
         defer = self.defer_bn_running
+        rep = self.bn_repeat
+        assert not (defer and (groups > 1 or rep > 1)), "deferred running statistics are a single-group mechanism"
         L.check(self.lib.isa_bn_finalize(L.ptr(stats), count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                          None if defer else P.ptr(pre + ".running_mean"),
                                          None if defer else P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
-                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, self.st()),
+                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, groups, rep, self.st()),
                 "isa_bn_finalize")
         if defer:
             self.bn_running_queue.append((stats, count, pre, c))
-        P.int_buffers[pre + ".num_batches_tracked"] += 1
+        P.int_buffers[pre + ".num_batches_tracked"] += groups * rep
 
     def defer_handle(self):
         """isa_slab_arena* for the weight-gradient entry points while a backward pass runs, else NULL."""
@@ -607,7 +618,7 @@ class Engine:
             L.check(self.lib.isa_bn_finalize(None, 1.0, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
-                                             L.ptr(invstd), scale.numel(), self.st()), "isa_bn_finalize(eval refresh)")
+                                             L.ptr(invstd), scale.numel(), 1, 1, self.st()), "isa_bn_finalize(eval refresh)")
         self.eval_bn_stale = False
 
     def scratch(self, numel) -> torch.Tensor:
@@ -617,9 +628,25 @@ class Engine:
     def f32(self, *shape):
         return self.arena.alloc(shape, torch.float32)
 
-    def new_act(self, n, h, w, c, ld=None, dtype=None):
+    def new_act(self, n, h, w, c, ld=None, dtype=None, groups=1):
         ld = rup(c, 8) if ld is None else ld
-        return Act(self.arena.alloc((n, h, w, ld), dtype or self.dtype), 0, c)
+        return Act(self.arena.alloc((n, h, w, ld), dtype or self.dtype), 0, c, groups=groups)
+
+    def like(self, x: Act, c, ld=None, n=None):
+        """A new activation with x's batch, spatial size and statistic groups."""
+        return self.new_act(x.n if n is None else n, x.h, x.w, c, ld, groups=x.groups)
+
+    @contextlib.contextmanager
+    def repeated(self, times):
+        """The enclosed layers stand for `times` identical evaluations of the reference (same input, same weights, train-mode
+        batch statistics: the `cross` block ahead of its Dropout2d in every decoder iteration, utils.py:984): computed
+        once, their BatchNorm running statistics and num_batches_tracked advance `times` times."""
+        prev = self.bn_repeat
+        self.bn_repeat = times
+        try:
+            yield
+        finally:
+            self.bn_repeat = prev
 
     def st(self):
         return L.stream_ptr()
@@ -670,7 +697,7 @@ class Engine:
             L.check(self.lib.isa_bn_finalize(None, 1.0, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(cached[0]), L.ptr(cached[1]),
-                                             L.ptr(cached[2]), L.ptr(cached[3]), c, self.st()), "isa_bn_finalize")
+                                             L.ptr(cached[2]), L.ptr(cached[3]), c, 1, 1, self.st()), "isa_bn_finalize")
         return cached
 
     def conv_bn_eval(self, x: Act, wname, out: Act, bn_pre, act, res: Optional[Act] = None, taps=1):
@@ -695,7 +722,7 @@ class Engine:
         reg = self.reg_conv(wname, taps, kmap, transposed)
         in_mode = L.IN_3X3 if taps == 9 else L.IN_1X1
         out_mode = L.OUT_SHUFFLE2 if transposed else L.OUT_PLAIN
-        st = self.scratch(2 * out.c * STAT_R) if stats else None
+        st = self.scratch(2 * out.c * STAT_R * out.groups) if stats else None
         job = (x, reg, bias, out, in_mode, out_mode, st)
         self._launch_conv(*job)
         self._last_conv = dict(reg=reg, in_mode=in_mode)
@@ -770,7 +797,7 @@ class Engine:
         ydesc = self._bn_desc(yb, red=yred)
         xdesc = None
         if xb is not None:
-            xred = self.scratch(2 * x.c * STAT_R)
+            xred = self.scratch(2 * x.c * STAT_R * x.groups)
             xdesc = self._bn_desc(xb, out_red=xred, with_params=False)
             xb["red_done"] = xred
         acc = self.grads.claim(x, self)
@@ -803,7 +830,7 @@ class Engine:
         reg = self.reg_dw(wname, kmap)
         if self.packer.table is None:
             self.packer.pack()
-        st = self.scratch(2 * out.c * STAT_R) if stats else None
+        st = self.scratch(2 * out.c * STAT_R * out.groups) if stats else None
         if self.profile:
             self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
         L.check(self.lib.isa_dwconv3x3(x.d(), x.p(), self.packer.ptr(reg["fwd"]),
@@ -838,7 +865,7 @@ class Engine:
                     ydesc = self._bn_desc(yb, red=yred)
                     xdesc = None
                     if xb is not None:
-                        xred = self.scratch(2 * x.c * STAT_R)
+                        xred = self.scratch(2 * x.c * STAT_R * x.groups)
                         xdesc = self._bn_desc(xb, out_red=xred, with_params=False)
                         xb["red_done"] = xred
                     acc = self.grads.claim(x, self)
@@ -872,24 +899,26 @@ class Engine:
         """Lazy BN(+act): returns a view of `raw` whose prologue applies scale/shift/act.
         Gradient w.r.t. the lazy tensor is converted in place to the gradient w.r.t. `raw`."""
         c = raw.c
-        count = float(raw.n * raw.h * raw.w) if count is None else float(count)
+        G = raw.groups
+        count = float(raw.n // G * raw.h * raw.w) if count is None else float(count)     # per statistic group
         P = self.params
         train = self.bn_train
+        assert train or G == 1, "statistic groups exist in train mode only (eval statistics are shared)"
         cached = None if train else self.eval_bn_cache.get(pre)
         if cached is not None:
             scale, shift, mean, invstd = cached
         elif train:
-            scale, shift, mean, invstd = (self.f32(c) for _ in range(4))
+            scale, shift, mean, invstd = (self.f32(G * c) for _ in range(4))
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
         if train:
-            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd)
+            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
         elif cached is None:
             L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
-                                             L.ptr(invstd), c, self.st()), "isa_bn_finalize")
+                                             L.ptr(invstd), c, 1, 1, self.st()), "isa_bn_finalize")
         lazy = raw.with_pro(Pro(scale, shift, act))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
@@ -921,7 +950,7 @@ class Engine:
         red = b.pop("red_done", None)
         nb = lazy.n * lazy.h * lazy.w * lazy.c * lazy.buf.element_size()
         if b["train"] and red is None:
-            red = self.scratch(2 * lazy.c * STAT_R)
+            red = self.scratch(2 * lazy.c * STAT_R * lazy.groups)
             if self.profile:
                 self.next_bytes = 2 * nb
             L.check(self.lib.isa_bn_bwd_reduce(dt.d(), b["raw"].d(), L.ptr(b["scale"]), L.ptr(b["shift"]),
@@ -940,26 +969,30 @@ class Engine:
 
     def bn_out(self, raw: Act, stats, pre, act, out: Act, res: Optional[Act] = None, bscale=None,
                count=None, res2: Optional[Act] = None, oscale=None) -> Act:
-        """Materialising BN: out = (act(BN(raw)) * bscale (+ res) (+ res2)) * oscale."""
+        """Materialising BN: out = (act(BN(raw)) * bscale (+ res) (+ res2)) * oscale.
+        Broadcast form (train mode): raw / res hold one statistic group, out has G of them with a per-image oscale each
+        (isa_affine_act_res); the gradient of the shared value is the oscale-weighted sum over the groups."""
         c = raw.c
-        count = float(raw.n * raw.h * raw.w) if count is None else float(count)
+        G = raw.groups
+        count = float(raw.n // G * raw.h * raw.w) if count is None else float(count)     # per statistic group
         P = self.params
         train = self.bn_train
+        assert train or G == 1, "statistic groups exist in train mode only (eval statistics are shared)"
         cached = None if train else self.eval_bn_cache.get(pre)
         if cached is not None:
             scale, shift, mean, invstd = cached
         elif train:
-            scale, shift, mean, invstd = (self.f32(c) for _ in range(4))
+            scale, shift, mean, invstd = (self.f32(G * c) for _ in range(4))
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
         if train:
-            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd)
+            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
         elif cached is None:
             L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
-                                             L.ptr(invstd), c, self.st()), "isa_bn_finalize")
+                                             L.ptr(invstd), c, 1, 1, self.st()), "isa_bn_finalize")
         lazy = raw.with_pro(Pro(scale, shift, act, bscale))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
@@ -971,11 +1004,14 @@ class Engine:
         if self.record:
             pw = self._pw_out.get((raw.buf.data_ptr(), raw.c0, raw.c)) if (train and bscale is None) else None
 
+            bcast = out.n != raw.n
+            assert not bcast or (oscale is not None and res2 is None and out.n == out.groups * raw.n and raw.groups == 1)
+
             def bwd():
                 dout = self.grads.grad_of(out)
                 dsum = dout
-                if oscale is not None:           # d(sum) = dout * dropout mask
-                    dsum = self.new_act(out.n, out.h, out.w, out.c)
+                if oscale is not None:           # d(sum) = dout * dropout mask (summed over the groups of a broadcast)
+                    dsum = self.like(raw, out.c)
                     L.check(self.lib.isa_scale_bc(dout.d(), L.ptr(oscale), dsum.d(), 0, self.st()), "isa_scale_bc")
                 for r in (res, res2):
                     if r is not None and r.needs_grad:

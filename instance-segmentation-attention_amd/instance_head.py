@@ -39,6 +39,11 @@ class InstanceHead:
         # concurrent HIP streams for the pyramid passes: 1 = none, 2 = odd iterations on a side stream, 3 = cross
         # chains on the step's stream + one side stream per iteration's level chain (see forward)
         self.streams = int(os.environ.get("ISA_STREAMS", "2"))
+        # all decoder iterations of a train-mode pass as ONE batch of max_iter * B images with a BatchNorm statistic group
+        # per iteration (attenet2.py:384-399 runs them one after the other through the same weights): half the launches,
+        # twice the work per launch on the low-resolution levels.  0 = one pass per iteration (A/B, bisecting).
+        self.batch_iters = os.environ.get("ISA_BATCH_ITERS", "1") != "0"
+        self.injected_masks = None       # {(iteration, level, "cross"|"d1"|"d2"): [n, C] keep/(1-p) mask}: parity by injection
         self.sample_in_training = True   # False: greedy point (argmax) also in training; parity tests inject s_t instead
         import ctypes as _C
         self._level_w = (_C.c_float * 5)(*PYRAMID_W)
@@ -87,7 +92,7 @@ class InstanceHead:
         L.check(E.lib.isa_bn_finalize(L.ptr(stats) if E.bn_train else None, float(n * Lp), P.ptr(pre + ".bn.weight"),
                                       P.ptr(pre + ".bn.bias"), P.ptr(pre + ".bn.running_mean"),
                                       P.ptr(pre + ".bn.running_var"), E.BN_MOMENTUM, E.BN_EPS, L.ptr(scale),
-                                      L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, E.st()), "isa_bn_finalize")
+                                      L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, 1, 1, E.st()), "isa_bn_finalize")
         out = E.new_act(n, x.h, x.w, c)
         L.check(E.lib.isa_sp_apply(x.d(), L.ptr(beta), L.ptr(sem), L.ptr(scale), L.ptr(shift), out.d(), E.st()),
                 "isa_sp_apply")
@@ -171,6 +176,46 @@ class InstanceHead:
         self._mask_pool = torch.empty_like(u)
         L.check(self.E.lib.isa_dropout_mask(L.ptr(u), total, keep, L.ptr(self._mask_pool), self.E.st()), "isa_dropout_mask")
 
+    def _masks_batched(self, n, G, training):
+        """Dropout2d masks of a pass that batches the G iterations: per level {cross, d1, d2} as [G*n, C] arrays
+        ([iteration][image] rows, the order the batched tensors use).  Inactive d1 / d2 masks are absent; an inactive
+        cross mask is all ones (the broadcast materialising pass always takes a per-image scale)."""
+        E = self.E
+        keep = 1.0 - self.drop_rate
+        act_cross = self.drop_rate > 0 and E.bn_train
+        act_d = self.drop_rate > 0 and training
+        inj = self.injected_masks
+        out = []
+        pool, cur = None, 0
+        if inj is None and (act_cross or act_d):
+            total = sum((int(act_cross) + 2 * int(act_d)) * G * n * oc for oc in OUT_CH)
+            u = torch.rand(total, device=E.device)
+            pool = torch.empty_like(u)
+            L.check(E.lib.isa_dropout_mask(L.ptr(u), total, keep, L.ptr(pool), E.st()), "isa_dropout_mask")
+
+        def take(lvl, kind, oc):
+            nonlocal cur
+            if inj is not None:
+                return torch.cat([inj[it, lvl, kind].to(E.device, torch.float32).reshape(n, oc) for it in range(G)]).contiguous()
+            m = pool[cur:cur + G * n * oc].view(G * n, oc)
+            cur += G * n * oc
+            return m
+
+        for lvl, oc in enumerate(OUT_CH):
+            masks = {}
+            if act_cross:
+                masks["cross"] = take(lvl, "cross", oc)
+            else:
+                ones = getattr(self, "_ones", None)
+                if ones is None or ones.numel() < G * n * oc:
+                    ones = self._ones = torch.ones(G * n * max(OUT_CH), device=E.device)
+                masks["cross"] = ones[:G * n * oc].view(G * n, oc)
+            if act_d:
+                masks["d1"] = take(lvl, "d1", oc)
+                masks["d2"] = take(lvl, "d2", oc)
+            out.append(masks)
+        return out
+
     def _drop_mask(self, n, c, active):
         if not active or self.drop_rate <= 0:
             return None
@@ -178,10 +223,13 @@ class InstanceHead:
         self._mask_cursor += n * c
         return m
 
-    def level_cross(self, lvl, skip: Act, masks):
+    def level_cross(self, lvl, skip: Act, masks, G=1):
         """The `cross` branch of one UpAttenLayer (utils.py:1058-1075): IR -> Dropout2d(module) -> IR on the backbone
         feature.  It does not depend on the previous level, so it runs on its own stream next to the level chain.
-        Returns the concat buffer (its cross slice written) and the slice geometry."""
+        Returns the concat buffer (its cross slice written).
+        G > 1 (all decoder iterations in one pass): the first block sees the same input and weights in every
+        iteration, so it is evaluated ONCE (E.repeated(G): running statistics advance G times) and only its Dropout2d
+        differs - the materialising pass writes G masked copies (masks["cross"] is [G*n, C])."""
         E, net = self.E, self.net
         ua = "decoder.bone.upAtten%d.UpAtten" % lvl
         n, h, w = skip.n, skip.h, skip.w
@@ -190,15 +238,21 @@ class InstanceHead:
         naux = 2 * nb + 2
         ccross = out_ch - naux
         width = out_ch if lvl == 0 else 2 * out_ch
-        cat = E.new_act(n, h, w, width, ld=width)
+        cat = E.new_act(G * n, h, w, width, ld=width, groups=G)
         cross_off = 0 if lvl == 0 else out_ch
-        mid = E.new_act(n, h, w, out_ch)
-        net.block_ir(skip, ua + ".cross.up_feature.0", mid, oscale=masks.get("cross"))
+        mid = E.new_act(G * n, h, w, out_ch, groups=G)
+        if G > 1:
+            with E.repeated(G):
+                net.block_ir(skip, ua + ".cross.up_feature.0", mid, oscale=masks["cross"])
+        else:
+            net.block_ir(skip, ua + ".cross.up_feature.0", mid, oscale=masks.get("cross"))
         net.block_ir(mid, ua + ".cross.up_feature.2", cat.slice(cross_off, ccross))
         return cat
 
     def level_main(self, lvl, cat: Act, x_prev: Act, pred_prev: Act, mask_all, s_t, W_full, training, masks):
-        """The rest of one UpDecoderLayer (utils.py:869-892) once the cross slice of `cat` is there.  Returns (x, pred)."""
+        """The rest of one UpDecoderLayer (utils.py:869-892) once the cross slice of `cat` is there.  Returns (x, pred).
+        With cat.groups > 1 the batch holds all decoder iterations ([iteration][image]); mask_all is the one map per
+        image they share, s_t and the masks are per (iteration, image)."""
         E, net = self.E, self.net
         pre = "decoder.bone.upAtten%d" % lvl
         ua = pre + ".UpAtten"
@@ -210,7 +264,7 @@ class InstanceHead:
         cross_off = 0 if lvl == 0 else out_ch
         up = None
         if lvl > 0:
-            up = E.new_act(n, h, w, out_ch)
+            up = E.like(cat, out_ch)
             E.conv(x_prev, ua + ".up.weight", up, bias=ua + ".up.bias", transposed=True)
             gated = cat.slice(0, out_ch)
             gmap = E.f32(n * h * w) if E.record else None
@@ -225,29 +279,30 @@ class InstanceHead:
                             "isa_gate_bwd")
                 E.tape.append(bwd_gate)
         aux = cat.slice(cross_off + ccross, naux)
-        L.check(E.lib.isa_concat_aux(aux.d(), L.ptr(mask_all), L.ptr(s_t), W_full, f, nb, E.st()), "isa_concat_aux")
+        L.check(E.lib.isa_concat_aux(aux.d(), L.ptr(mask_all), L.ptr(s_t), W_full, f, nb, n // cat.groups, E.st()),
+                "isa_concat_aux")
         if lvl == 0:
             kmap = None
         else:   # physical [gated(out) | cross(ccross) | aux] -> source [cross | gated | aux]
             kmap = [ccross + k for k in range(out_ch)] + list(range(ccross)) + \
                    [ccross + out_ch + k for k in range(naux)]
-        y = E.new_act(n, h, w, out_ch)
+        y = E.like(cat, out_ch)
         _, s = E.conv(cat, ua + ".conv1.0.weight", y, stats=True, kmap=kmap)
-        x = E.new_act(n, h, w, out_ch)
+        x = E.like(cat, out_ch)
         E.bn_out(y, s, ua + ".conv1.1", L.ACT_RELU, x, bscale=masks.get("d1"))
-        x2 = E.new_act(n, h, w, out_ch)
+        x2 = E.like(cat, out_ch)
         net.block_ir(x, ua + ".dilation_part1.0", x2)
-        x3 = E.new_act(n, h, w, out_ch)
+        x3 = E.like(cat, out_ch)
         self._block_ir_ext(x2, ua + ".dilation_part1.1", x3, res2=up, oscale=masks.get("d2"))
-        x4 = E.new_act(n, h, w, out_ch)
+        x4 = E.like(cat, out_ch)
         net.block_ir(x3, ua + ".dilation_part2.0", x4)
-        x5 = E.new_act(n, h, w, out_ch)
+        x5 = E.like(cat, out_ch)
         net.block_ir(x4, ua + ".dilation_part2.1", x5)
         # L0Layer (utils.py:696-774): conv3x3 -> LeakyReLU -> conv3x3
-        hmid = E.new_act(n, h, w, out_ch // 2)
+        hmid = E.like(cat, out_ch // 2)
         E.conv(x5, pre + ".pred.l_i.weight", hmid, taps=9, bias=pre + ".pred.l_i.bias")
-        pred = E.new_act(n, h, w, 2)
-        hact = E.act_out(hmid, L.ACT_LEAKY, E.new_act(n, h, w, out_ch // 2))     # once, not once per tap
+        pred = E.like(cat, 2)
+        hact = E.act_out(hmid, L.ACT_LEAKY, E.like(cat, out_ch // 2))     # once, not once per tap
         E.conv(hact, pre + ".pred.last_fc.1.weight", pred, taps=9, bias=pre + ".pred.last_fc.1.bias")
         return x5, pred
 
@@ -257,13 +312,13 @@ class InstanceHead:
         E = self.E
         chid = E.params.shapes[pre + ".conv.0.weight"][0]
         cout = E.params.shapes[pre + ".conv.6.weight"][0]
-        y1 = E.new_act(x.n, x.h, x.w, chid)
+        y1 = E.like(x, chid)
         _, s1 = E.conv(x, pre + ".conv.0.weight", y1, stats=True)
         y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
-        y2 = E.new_act(x.n, x.h, x.w, chid)
+        y2 = E.like(x, chid)
         _, s2 = E.dwconv(y1, pre + ".conv.3.weight", y2, stats=True)
         y2 = E.bn(y2, s2, pre + ".conv.4", L.ACT_RELU6)
-        y3 = E.new_act(x.n, x.h, x.w, cout)
+        y3 = E.like(x, cout)
         _, s3 = E.conv(y2, pre + ".conv.6.weight", y3, stats=True)
         return E.bn_out(y3, s3, pre + ".conv.7", L.ACT_NONE, out, res=x if x.c == cout else None,
                         res2=res2, oscale=oscale)
@@ -289,7 +344,7 @@ class InstanceHead:
                 mask_all.append(sem_map)
             else:
                 m = E.f32(n * (H // f) * (W // f))
-                L.check(E.lib.isa_pool_target(None, None, L.ptr(sem_map), nobj, n, H, W, f, L.ptr(m), E.st()),
+                L.check(E.lib.isa_pool_target(None, None, L.ptr(sem_map), nobj, n, H, W, f, L.ptr(m), n, E.st()),
                         "isa_pool_target(sem)")
                 mask_all.append(m)
         if idx_dev is None:          # [max_iter, n] int32 instance order; pre-staged by the graph-captured step
@@ -301,6 +356,9 @@ class InstanceHead:
             self.baseline = torch.zeros(1, dtype=torch.float32, device=E.device)
         if capture is not None:
             capture.update(x_enc=x_enc, s_sp=s, merge=merge)
+        if self.batch_iters and E.bn_train and 2 <= max_iter <= 4:
+            return self._forward_batched(x_enc, merge, skips, sem_map, ins, n, H, W, nobj, max_iter, training, idx_dev,
+                                         injected_s_t, capture, mask_all, scal)
         self._draw_masks(n, max_iter, training)
         # ---- per-iteration front: instance softmax, glimpse point, pyramid targets (main stream) ----------------
         pre = []
@@ -308,7 +366,7 @@ class InstanceHead:
             idx = idx_dev[it]
             alpha, rowstat = E.f32(n * Lp), E.f32(2 * n)
             L.check(E.lib.isa_ins_softmax(L.ptr(merge), L.ptr(ins), L.ptr(idx), n, nobj, Lp, L.ptr(alpha),
-                                          L.ptr(rowstat), E.st()), "isa_ins_softmax")
+                                          L.ptr(rowstat), n, E.st()), "isa_ins_softmax")
             if injected_s_t is not None:
                 s_t = injected_s_t[it]
             else:
@@ -323,7 +381,7 @@ class InstanceHead:
             targets = []
             for f in FACTORS:
                 t = E.f32(n * (H // f) * (W // f))
-                L.check(E.lib.isa_pool_target(L.ptr(ins), L.ptr(idx), None, nobj, n, H, W, f, L.ptr(t), E.st()),
+                L.check(E.lib.isa_pool_target(L.ptr(ins), L.ptr(idx), None, nobj, n, H, W, f, L.ptr(t), n, E.st()),
                         "isa_pool_target")
                 targets.append(t)
             sums_all = E.scratch(5 * 8 * n)                 # [level][image][8], contiguous for isa_head_loss
@@ -400,7 +458,7 @@ class InstanceHead:
             coef, adv = E.f32(5 * 4 * n), E.f32(n)
             L.check(E.lib.isa_head_loss(L.ptr(sums_all), L.ptr(alpha), L.ptr(s_t), Lp, n, self._level_w, CE_WEIGHT,
                                         LAMBDA_L, LAMBDA_R, 1.0 / max_iter, L.ptr(self.baseline), 1 if training else 0,
-                                        L.ptr(coef), L.ptr(adv), L.ptr(scal), E.st()), "isa_head_loss")
+                                        L.ptr(coef), L.ptr(adv), L.ptr(scal), 1, E.st()), "isa_head_loss")
             if E.record:
                 def bwd_losses(preds=preds, targets=targets, coef=coef, alpha=alpha, idx=idx, s_t=s_t, adv=adv):
                     for lvl in range(5):
@@ -409,10 +467,85 @@ class InstanceHead:
                                                          L.ptr(coef[lvl * 4 * n:(lvl + 1) * 4 * n]),
                                                          E.grads.grad_of(preds[lvl]).d(), acc, E.st()), "isa_mask_loss_grad")
                     L.check(E.lib.isa_ins_softmax_bwd(L.ptr(alpha), L.ptr(ins), L.ptr(idx), L.ptr(s_t), L.ptr(adv), n, nobj,
-                                                      Lp, L.ptr(self.dmerge), E.st()), "isa_ins_softmax_bwd")
+                                                      Lp, L.ptr(self.dmerge), n, E.st()), "isa_ins_softmax_bwd")
                 E.tape.append(bwd_losses)
             iters.append(dict(idx=idx, alpha=alpha, s_t=s_t, targets=targets, preds=preds, sums=sums))
         return dict(iters=iters, max_iter=max_iter, merge=merge, x_enc=x_enc, scal=scal)
+
+    def _forward_batched(self, x_enc, merge, skips, sem_map, ins, n, H, W, nobj, G, training, idx_dev, injected_s_t,
+                         capture, mask_all, scal):
+        """The G decoder iterations as one pass over G*n images, rows ordered [iteration][image] (attenet2.py:384-399
+        runs them one after the other; they share weights and backbone features and do not read each other's outputs).
+        BatchNorm statistics stay per iteration (isa_tensor.groups = G), running statistics take the G updates in
+        iteration order inside isa_bn_finalize, the REINFORCE baseline EMA runs in iteration order inside isa_head_loss.
+        The cross branches (backbone features only) run beside the level chain on side stream 1 (ISA_STREAMS >= 2)."""
+        E = self.E
+        Lp, R = H * W, G * n
+        idx_flat = idx_dev.reshape(-1).contiguous()          # [G*n]
+        alpha, rowstat = E.f32(R * Lp), E.f32(2 * R)
+        L.check(E.lib.isa_ins_softmax(L.ptr(merge), L.ptr(ins), L.ptr(idx_flat), R, nobj, Lp, L.ptr(alpha), L.ptr(rowstat), n,
+                                      E.st()), "isa_ins_softmax")
+        s_t = E.arena.alloc((R,), torch.int32)
+        if injected_s_t is not None:
+            for it in range(G):
+                s_t[it * n:(it + 1) * n].copy_(injected_s_t[it])
+        else:
+            race = None                                      # attenet2.py:304-321 `sample`, see the per-iteration path
+            if training and self.sample_in_training:
+                race = torch.empty(R, Lp, dtype=torch.float32, device=alpha.device).exponential_(1.0)
+            L.check(E.lib.isa_row_argmax(L.ptr(alpha), L.ptr(race), R, Lp, L.ptr(s_t), E.st()), "isa_row_argmax")
+        targets = []
+        for f in FACTORS:
+            t = E.f32(R * (H // f) * (W // f))
+            L.check(E.lib.isa_pool_target(L.ptr(ins), L.ptr(idx_flat), None, nobj, R, H, W, f, L.ptr(t), n, E.st()),
+                    "isa_pool_target")
+            targets.append(t)
+        sums_all = E.scratch(5 * 8 * R)                      # [level][iteration][image][8]
+        masks = self._masks_batched(n, G, training)
+        sc = 1 if self.streams >= 2 else 0                   # the cross chain's stream
+        if sc:
+            for sk in skips:
+                E.grads.share(sk)
+            if E.record:
+                E.tape.append(lambda: E.grads.merge_shared(E))
+            E.sync(0, sc)
+        x = pred = None
+        preds = []
+        for lvl in range(5):
+            with E.on(sc):
+                cat = self.level_cross(lvl, skips[lvl], masks[lvl], G)
+            E.sync(sc, 0)
+            x, pred = self.level_main(lvl, cat, x, pred, mask_all[lvl], s_t, W, training, masks[lvl])
+            L.check(E.lib.isa_mask_loss_sums(pred.d(), L.ptr(targets[lvl]), None, L.ptr(sums_all[lvl * 8 * R:(lvl + 1) * 8 * R]),
+                                             E.st()), "isa_mask_loss_sums")
+            preds.append(pred)
+            if capture is not None:
+                for it in range(G):
+                    capture["it%d.L%d.x" % (it, lvl)] = x.images(it * n, n)
+                    capture["it%d.L%d.pred" % (it, lvl)] = pred.images(it * n, n)
+        coef, adv = E.f32(5 * 4 * R), E.f32(R)
+        L.check(E.lib.isa_head_loss(L.ptr(sums_all), L.ptr(alpha), L.ptr(s_t), Lp, n, self._level_w, CE_WEIGHT, LAMBDA_L,
+                                    LAMBDA_R, 1.0 / G, L.ptr(self.baseline), 1 if training else 0, L.ptr(coef), L.ptr(adv),
+                                    L.ptr(scal), G, E.st()), "isa_head_loss")
+        if E.record:
+            def bwd_losses():
+                for lvl in range(5):
+                    acc = E.grads.claim(preds[lvl], E)
+                    L.check(E.lib.isa_mask_loss_grad(preds[lvl].d(), L.ptr(targets[lvl]), None,
+                                                     L.ptr(coef[lvl * 4 * R:(lvl + 1) * 4 * R]), E.grads.grad_of(preds[lvl]).d(),
+                                                     acc, E.st()), "isa_mask_loss_grad")
+                L.check(E.lib.isa_ins_softmax_bwd(L.ptr(alpha), L.ptr(ins), L.ptr(idx_flat), L.ptr(s_t), L.ptr(adv), R, nobj, Lp,
+                                                  L.ptr(self.dmerge), n, E.st()), "isa_ins_softmax_bwd")
+            E.tape.append(bwd_losses)
+        iters = []
+        for it in range(G):                                  # per-iteration views, as the one-pass-per-iteration path returns them
+            hw = [(H // f) * (W // f) for f in FACTORS]
+            iters.append(dict(idx=idx_flat[it * n:(it + 1) * n], alpha=alpha[it * n * Lp:(it + 1) * n * Lp],
+                              s_t=s_t[it * n:(it + 1) * n],
+                              targets=[targets[l][it * n * hw[l]:(it + 1) * n * hw[l]] for l in range(5)],
+                              preds=[p.images(it * n, n) for p in preds],
+                              sums=[sums_all[l * 8 * R + it * 8 * n:l * 8 * R + (it + 1) * 8 * n] for l in range(5)]))
+        return dict(iters=iters, max_iter=G, merge=merge, x_enc=x_enc, scal=scal)
 
     @staticmethod
     def order_tensor(selected_idx, max_iter, n):

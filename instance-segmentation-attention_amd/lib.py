@@ -22,7 +22,7 @@ _ERR = {-1: "ISA_EINVAL", -2: "ISA_EALIGN", -3: "ISA_EDTYPE", -4: "ISA_ELAUNCH",
 
 class IsaTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-                ("c", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32)]
+                ("c", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32), ("groups", C.c_int32)]
 
 
 class IsaPro(C.Structure):
@@ -76,7 +76,7 @@ SIGNATURES = {
     "isa_resize_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP],
     "isa_resize_bilinear_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP, I64, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],
-    "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, VP],
+    "isa_bn_finalize": [VP, F, VP, VP, VP, VP, F, F, VP, VP, VP, VP, I32, I32, I32, VP],
     "isa_bn_bwd_reduce": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP],
     "isa_bn_bwd_apply": [P_T, P_T, VP, VP, VP, VP, I32, VP, VP, VP, F, I32, P_T, VP, VP, VP],
     "isa_affine_act_res": [P_T, P_PRO, P_T, P_T, VP, P_T, VP],
@@ -95,19 +95,19 @@ SIGNATURES = {
     "isa_maskbn_stats": [P_T, VP, VP, VP, VP],
     "isa_maskbn_finalize": [VP, VP, I32, I32, VP, VP, VP, F, I32, VP],
     "isa_maskbn_apply_pool": [P_T, VP, VP, VP, VP, F, VP, VP],
-    "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, VP],
+    "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, I32, VP],
     "isa_row_argmax": [VP, VP, I32, I64, VP, VP],
     "isa_onehot_map": [VP, I32, I64, VP, VP],
     "isa_dropout_mask": [VP, I64, F, VP, VP],
     "isa_softmax_nchw": [P_T, VP, VP],
-    "isa_pool_target": [VP, VP, VP, I32, I32, I32, I32, I32, VP, VP],
-    "isa_concat_aux": [P_T, VP, VP, I32, I32, I32, VP],
+    "isa_pool_target": [VP, VP, VP, I32, I32, I32, I32, I32, VP, I32, VP],
+    "isa_concat_aux": [P_T, VP, VP, I32, I32, I32, I32, VP],
     "isa_gate": [P_T, P_T, P_T, VP, VP],
     "isa_mask_loss_sums": [P_T, VP, VP, VP, VP],
-    "isa_head_loss": [VP, VP, VP, I64, I32, VP, F, F, F, F, VP, I32, VP, VP, VP, VP],
+    "isa_head_loss": [VP, VP, VP, I64, I32, VP, F, F, F, F, VP, I32, VP, VP, VP, I32, VP],
     "isa_sem_loss": [VP, I32, VP, VP, VP],
     "isa_mask_loss_grad": [P_T, VP, VP, VP, P_T, I32, VP],
-    "isa_ins_softmax_bwd": [VP, VP, VP, VP, VP, I32, I32, I64, VP, VP],
+    "isa_ins_softmax_bwd": [VP, VP, VP, VP, VP, I32, I32, I64, VP, I32, VP],
     "isa_maskbn_bwd": [P_T, VP, VP, VP, VP, F, VP, I32, VP, VP, VP, VP, P_T, I32, VP],
     "isa_sp_bwd": [P_T, P_T, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, F, I32, VP, P_T, I32,
                    VP, VP, VP, VP, VP, VP, VP, VP],

@@ -25,14 +25,14 @@ class Network:
         E = self.E
         cin = x.c
         cout = E.params.shapes[pre + ".conv.3.weight"][0]
-        y1 = E.new_act(x.n, x.h, x.w, cin)
+        y1 = E.like(x, cin)
         if E.eval_fusable():                               # eval: BN.4 and the residual ride in the 1x1 conv's epilogue
             E.dwconv(x, pre + ".conv.0.weight", y1, stats=False)
             y1 = E.bn(y1, None, pre + ".conv.1", L.ACT_RELU6)
             return E.conv_bn_eval(y1, pre + ".conv.3.weight", out, pre + ".conv.4", L.ACT_NONE, res=x if cin == cout else None)
         _, s1 = E.dwconv(x, pre + ".conv.0.weight", y1, stats=True)
         y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
-        y2 = E.new_act(x.n, x.h, x.w, cout)
+        y2 = E.like(x, cout)
         _, s2 = E.conv(y1, pre + ".conv.3.weight", y2, stats=True)
         return E.bn_out(y2, s2, pre + ".conv.4", L.ACT_NONE, out, res=x if cin == cout else None)
 
@@ -44,21 +44,21 @@ class Network:
         cin = x.c
         chid = E.params.shapes[pre + ".conv.0.weight"][0]
         cout = E.params.shapes[pre + ".conv.6.weight"][0]
-        y1 = E.new_act(x.n, x.h, x.w, chid)
+        y1 = E.like(x, chid)
         if E.eval_fusable() and oscale is None:
             # eval: expand conv stores ReLU6(BN(.)) (no prologue in the depthwise conv), the project conv applies BN.7 and
             # the residual in its epilogue (no materialising pass)
             E.conv_bn_eval(x, pre + ".conv.0.weight", y1, pre + ".conv.1", L.ACT_RELU6)
-            y2 = E.new_act(x.n, x.h, x.w, chid)
+            y2 = E.like(x, chid)
             E.dwconv(y1, pre + ".conv.3.weight", y2, stats=False)
             y2 = E.bn(y2, None, pre + ".conv.4", L.ACT_RELU6)
             return E.conv_bn_eval(y2, pre + ".conv.6.weight", out, pre + ".conv.7", L.ACT_NONE, res=x if cin == cout else None)
         _, s1 = E.conv(x, pre + ".conv.0.weight", y1, stats=True)
         y1 = E.bn(y1, s1, pre + ".conv.1", L.ACT_RELU6)
-        y2 = E.new_act(x.n, x.h, x.w, chid)
+        y2 = E.like(x, chid)
         _, s2 = E.dwconv(y1, pre + ".conv.3.weight", y2, stats=True)
         y2 = E.bn(y2, s2, pre + ".conv.4", L.ACT_RELU6)
-        y3 = E.new_act(x.n, x.h, x.w, cout)
+        y3 = E.like(x, cout)
         _, s3 = E.conv(y2, pre + ".conv.6.weight", y3, stats=True)
         return E.bn_out(y3, s3, pre + ".conv.7", L.ACT_NONE, out, res=x if cin == cout else None,
                         oscale=oscale)
@@ -66,7 +66,7 @@ class Network:
     def double_v1(self, x: Act, pre: str, out: Act):
         E = self.E
         cmid = E.params.shapes[pre + ".conv.down_conv_0.conv.3.weight"][0]
-        mid = E.new_act(x.n, x.h, x.w, cmid)
+        mid = E.like(x, cmid)
         self.block_v1(x, pre + ".conv.down_conv_0", mid)
         return self.block_v1(mid, pre + ".conv.down_conv_1", out)
 

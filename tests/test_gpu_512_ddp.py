@@ -124,6 +124,6 @@ def test_world2_branch_of_the_graphed_step():
         m.mark_weights_dirty()
         tr1.train_step(x, sem, ins, n, selected_idx=order, injected_s_t=inj)
         torch.cuda.synchronize()
-        assert float((m.store.flat - p_e).abs().max()) > 1e-4
+        assert float((m.store.flat - p_e).abs().max()) > 2e-5      # Adadelta is nearly scale-invariant: eps and weight decay only
     finally:
         dist.destroy_process_group()
