@@ -168,7 +168,7 @@ class InstanceHead:
         """All Dropout2d masks of a step from ONE torch.rand draw (3 per level and iteration: utils.py:869-892).
         Per-mask draws were ~120 five-microsecond launches per step."""
         self._mask_pool, self._mask_cursor = None, 0
-        if self.drop_rate <= 0 or not (training or self.E.bn_train):
+        if self.drop_rate <= 0 or not (training or self.E.bn_train) or self.injected_masks is not None:
             return
         total = max_iter * sum(3 * n * oc for oc in OUT_CH)
         keep = 1.0 - self.drop_rate
@@ -216,9 +216,11 @@ class InstanceHead:
             out.append(masks)
         return out
 
-    def _drop_mask(self, n, c, active):
+    def _drop_mask(self, n, c, active, key=None):
         if not active or self.drop_rate <= 0:
             return None
+        if self.injected_masks is not None:
+            return self.injected_masks[key].to(self.E.device, torch.float32).reshape(n, c).contiguous()
         m = self._mask_pool[self._mask_cursor:self._mask_cursor + n * c].view(n, c)
         self._mask_cursor += n * c
         return m
@@ -415,8 +417,9 @@ class InstanceHead:
                 masks = {}
                 if self.drop_rate > 0:
                     oc = OUT_CH[lvl]
-                    masks = dict(cross=self._drop_mask(n, oc, E.bn_train), d1=self._drop_mask(n, oc, training),
-                                 d2=self._drop_mask(n, oc, training))
+                    masks = dict(cross=self._drop_mask(n, oc, E.bn_train, (it, lvl, "cross")),
+                                 d1=self._drop_mask(n, oc, training, (it, lvl, "d1")),
+                                 d2=self._drop_mask(n, oc, training, (it, lvl, "d2")))
                     masks = {k: v for k, v in masks.items() if v is not None}
                 masks_of[it, lvl] = masks
         state = [dict(x=None, pred=None, preds=[]) for _ in range(max_iter)]

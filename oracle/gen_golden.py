@@ -8,7 +8,9 @@ tensor name), loaded into the reference with load_state_dict(strict=True).
 
 Reference-side knobs touched (interpreter state only, nothing in /root/reference is edited):
   config.H/W   -> fixture size (the reference hard-codes 256, config.py:1)
-  config.drop_rate = 0 before construction (dropout parity is by injection)
+  config.drop_rate = 0 before construction for the plain cases; the `*_drop` cases keep the reference's .5
+                 (config.py:64) and replace nn.Dropout2d.forward / F.dropout2d by seeded per-(image, channel) keep masks
+                 that are recorded under inject/drop/ (dropout parity is by injection)
   decoder.getRandomIdx / torch.multinomial -> deterministic choices recorded in the fixture
   decoder.vis -> no-op (debug JPEG writer, needs cv2)
 """
@@ -35,9 +37,51 @@ def topk3(p, nsamp=1, *a, **k):
     return torch.topk(p, 3, dim=1).indices[:, 2:3]
 
 
-def build(reseg, config, size, use_ins, dtype):
+class DropRecorder:
+    """Stands in for nn.Dropout2d.forward (utils.py:984, the `cross` branch) and F.dropout2d (utils.py:1104-1110): the
+    same Bernoulli(keep) / keep channel mask torch draws, but from a seeded numpy stream and recorded in call order -
+    per decoder iteration and level: cross (module), d1, d2 (functional)."""
+
+    def __init__(self, p, seed=77):
+        self.p, self.rs = p, np.random.RandomState(seed)
+        self.masks, self.n_module, self.n_func = {}, 0, 0
+
+    def _mask(self, x, name):
+        keep = 1.0 - self.p
+        m = (self.rs.rand(x.shape[0], x.shape[1]) < keep).astype(np.float64) / keep
+        self.masks[name] = m.astype(np.float32)
+        return x * torch.from_numpy(m).to(x.dtype)[:, :, None, None]
+
+    def module_forward(self, mod, x):
+        if not mod.training:
+            return x
+        it, lvl = divmod(self.n_module, 5)
+        self.n_module += 1
+        return self._mask(x, "it%d.L%d.cross" % (it, lvl))
+
+    def functional(self, x, p=0.5, training=True, inplace=False):
+        if not training or p <= 0:
+            return x
+        it, r = divmod(self.n_func, 10)
+        self.n_func += 1
+        return self._mask(x, "it%d.L%d.d%d" % (it, r // 2, 1 + r % 2))
+
+    @contextlib.contextmanager
+    def installed(self):
+        F = torch.nn.functional
+        real_f, real_m = F.dropout2d, torch.nn.Dropout2d.forward
+        rec = self
+        F.dropout2d = self.functional
+        torch.nn.Dropout2d.forward = lambda mod, x: rec.module_forward(mod, x)
+        try:
+            yield self
+        finally:
+            F.dropout2d, torch.nn.Dropout2d.forward = real_f, real_m
+
+
+def build(reseg, config, size, use_ins, dtype, drop=0.0):
     config.H = config.W = size
-    config.drop_rate = 0
+    config.drop_rate = drop
     m = reseg.ReSeg(2, use_ins)
     sd = R.synth_state_dict(23, True)
     own = m.state_dict()
@@ -64,6 +108,7 @@ def hook_outputs(m, store_list):
 
 
 def run_case(reseg, config, name, size, batch, mode, dtype=torch.float32, seed=1):
+    drop = 0.5 if name.endswith("_drop") or "_drop_" in name else 0.0     # config.py:64
     store = {}
     x, sem, ins, n = R.synth_batch(batch, size, size, seed=seed)
     x = x.to(dtype)
@@ -83,8 +128,9 @@ def run_case(reseg, config, name, size, batch, mode, dtype=torch.float32, seed=1
         pack_bits("sem_prob_gt_half", torch.softmax(sem_out, 1)[:, 1] > 0.5, store)
         return store
 
-    m = build(reseg, config, size, True, dtype)
+    m = build(reseg, config, size, True, dtype, drop)
     training = mode == "train"
+    dropper = DropRecorder(drop) if drop > 0 else None
     m.train(training)
     order = [list(reversed(range(int(k)))) for k in n.view(-1)]
     m.decoder.getRandomIdx = lambda n_ins: [list(s) for s in order]
@@ -103,7 +149,7 @@ def run_case(reseg, config, name, size, batch, mode, dtype=torch.float32, seed=1
     real_multinomial = torch.multinomial
     torch.multinomial = topk3
     try:
-        with contextlib.redirect_stdout(io.StringIO()):
+        with contextlib.redirect_stdout(io.StringIO()), (dropper.installed() if dropper else contextlib.nullcontext()):
             if training:
                 out = m(True, x, sem, ins, n)
             else:
@@ -121,6 +167,10 @@ def run_case(reseg, config, name, size, batch, mode, dtype=torch.float32, seed=1
     store["scalars/ins_ce_loss"] = np.array([float(ins_ce)])
     store["scalars/ins_dice_loss"] = np.array([float(ins_dice)])
     store["inject/s_t"] = np.array(s_ts, dtype=np.int64)
+    if dropper:
+        assert dropper.n_module == 5 * len(s_ts) and dropper.n_func == 10 * len(s_ts), (dropper.n_module, dropper.n_func)
+        for k_, v_ in dropper.masks.items():
+            store["inject/drop/" + k_] = v_
     it = {}
     for key, o in rec:
         if key == "unet":
@@ -168,6 +218,7 @@ def byname_cases(store):
     """a19-a21: the reference's own (dead-at-HEAD) attention operator classes."""
     from modules import utils as U   # /root/reference/code/lib/archs/modules/utils.py
     rs = np.random.RandomState(5)
+    torch.manual_seed(5)             # the operator classes draw their initial weights from torch's generator
     # a19: ScaledDotProductAttention with one query point against L keys (utils.py:305-329)
     bh, L, d = 4, 1024, 12
     q = torch.from_numpy(rs.standard_normal((bh, 1, d)).astype(np.float32))
@@ -239,6 +290,11 @@ def main():
         ("train_64_f64", 64, 2, "train", torch.float64),
         ("train_256", 256, 2, "train", torch.float32),
         ("train_256_f64", 256, 2, "train", torch.float64),     # the reference's own fp64 run: gradient floor at 256^2
+        # Dropout2d ACTIVE at the reference's rate (the configuration train.py and bench.py run): masks injected
+        ("train_64_drop", 64, 2, "train", torch.float32),
+        ("train_64_drop_f64", 64, 2, "train", torch.float64),
+        ("train_256_drop", 256, 2, "train", torch.float32),
+        ("train_256_drop_f64", 256, 2, "train", torch.float64),
     ]
     only = set(sys.argv[1:])              # python oracle/gen_golden.py [case ...]: regenerate a subset
     for name, size, batch, mode, dtype in cases:

@@ -41,5 +41,5 @@ for name, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:14]:
 print()
 print("%-32s %10s %6s %9s %9s %8s" % ("entry point", "MB/launch", "calls", "total ms", "avg us", "GB/s"))
 rows = sorted(((k, v) for k, v in groups.items() if which in k[0]), key=lambda kv: -kv[1][1])
-for (name, nb), (c, t) in rows[:40]:
+for (name, nb), (c, t) in rows[:int(os.environ.get("SHAPES_ROWS", "40"))]:
     print("%-32s %10.2f %6d %9.3f %9.1f %8.0f" % (name, nb / 1e6, c, t, t / c * 1e3, nb / 1e9 / (t / c * 1e-3) if nb else 0))

@@ -33,12 +33,27 @@ def load(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 
 
-def build(ReSeg, use_ins, dtype, train):
+def drop_masks(z):
+    """{(iteration, level, kind): [n, C] keep mask} recorded by the reference run of a *_drop fixture (gen_golden.py)."""
+    out = {}
+    for k in z.files:
+        if k.startswith("inject/drop/"):
+            it, lvl, kind = k[len("inject/drop/"):].split(".")
+            out[int(it[2:]), int(lvl[1:]), kind] = torch.from_numpy(z[k])
+    return out
+
+
+def build(ReSeg, use_ins, dtype, train, z=None):
     m = ReSeg(2, use_ins, dtype=dtype)
     sd = R.synth_state_dict(23, use_ins)
     m.load_state_dict(sd)
     m.train(train)
-    m.head.drop_rate = 0.0
+    masks = drop_masks(z) if z is not None else {}
+    if masks:                               # Dropout2d active at the reference's rate (config.py:64), masks injected
+        assert m.head.drop_rate == 0.5
+        m.head.injected_masks = masks
+    else:
+        m.head.drop_rate = 0.0
     return m, sd
 
 
@@ -118,7 +133,7 @@ def _run_gt(ReSeg, z, dtype, training):
     size, batch, seed = (int(v) for v in z["meta/size_batch_seed"])
     x, sem, ins, n = R.synth_batch(batch, size, size, seed=seed)
     sel = [[int(v) for v in row if v >= 0] for row in z["inject/selected_idx"]]
-    m, sd = build(ReSeg, True, dtype, training)
+    m, sd = build(ReSeg, True, dtype, training, z)
     inj = None
     if training:
         inj = [torch.tensor(row, dtype=torch.int32, device="cuda") for row in z["inject/s_t"]]
@@ -128,7 +143,8 @@ def _run_gt(ReSeg, z, dtype, training):
     return m, out, cap
 
 
-@pytest.mark.parametrize("case,training", [("evalgt_64", False), ("train_64", True)])
+@pytest.mark.parametrize("case,training", [("evalgt_64", False), ("train_64", True),
+                                           ("train_64_drop", True), ("train_256_drop", True)])    # Dropout2d p=.5 active
 def test_forward_with_gt_vs_reference_golden(case, training):
     ReSeg = need_gpu()
     z = load(case)

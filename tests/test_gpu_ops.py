@@ -316,10 +316,11 @@ def _run_backward(eng, out_act, dy, Act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("bscale", [False, True])      # per-image channel multiplier in the prologue: a Dropout2d mask
 @pytest.mark.parametrize("kind,cin,cout,hw", [("1x1", 32, 32, 16), ("1x1", 64, 246, 8), ("1x1", 48, 24, 12),
                                               ("1x1", 256, 128, 8), ("3x3", 32, 16, 12), ("3x3", 16, 2, 16),
                                               ("T", 64, 32, 8), ("dw", 32, 32, 16), ("dw", 21, 21, 10)])
-def test_conv_backward(dtype, kind, cin, cout, hw):
+def test_conv_backward(dtype, kind, cin, cout, hw, bscale):
     L, Act, Engine, ParamStore, Pro = _gpu()
     batch = 2
     taps = 9 if kind == "3x3" else 1
@@ -336,7 +337,10 @@ def test_conv_backward(dtype, kind, cin, cout, hw):
     eng = make_engine(Engine, ParamStore, [("w", w.shape), ("b", b.shape)], dict(w=w, b=b), dtype)
     eng.begin(bn_train=True, record=True)
     # lazy input: act(scale*x+shift) with ReLU6, as after a BN; data gradient is w.r.t. that value
-    xa = to_act(Act, x, dtype).with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6))
+    # bscale: keep / (1 - p) per (image, channel), as F.dropout2d(p=.5) scales (utils.py:1104-1110); Act.grad is the
+    # gradient w.r.t. the tensor's true value, i.e. after the multiplier
+    bs = ((torch.rand(batch, cin, generator=torch.Generator().manual_seed(11)) < 0.5).float() * 2.0) if bscale else None
+    xa = to_act(Act, x, dtype).with_pro(Pro(sc.cuda(), sh.cuda(), L.ACT_RELU6, bs.cuda() if bscale else None))
     oh, ow = (2 * hw, 2 * (hw + 2)) if kind == "T" else (hw, hw + 2)
     ya = eng.new_act(batch, oh, ow, cout)
     if kind == "dw":
@@ -347,6 +351,8 @@ def test_conv_backward(dtype, kind, cin, cout, hw):
     _run_backward(eng, ya, dy, Act)
     # reference
     xt = torch.clamp(q(x, dtype) * sc[None, :, None, None] + sh[None, :, None, None], 0, 6)
+    if bscale:
+        xt = xt * bs[:, :, None, None]
     if dtype == torch.bfloat16 and kind != "dw":
         xt = q(xt, dtype)                       # the MFMA operand is rounded once to bf16
     xt.requires_grad_(True)

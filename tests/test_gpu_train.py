@@ -36,7 +36,13 @@ def setup(ReSeg, Trainer, z, dtype):
     m = ReSeg(2, True, dtype=dtype)
     m.load_state_dict(R.synth_state_dict(23, True))
     m.train()
-    m.head.drop_rate = 0.0
+    from test_gpu_model import drop_masks
+    masks = drop_masks(z)
+    if masks:                               # *_drop fixtures: Dropout2d active at the reference's rate, masks injected
+        assert m.head.drop_rate == 0.5
+        m.head.injected_masks = masks
+    else:
+        m.head.drop_rate = 0.0
     inj = [torch.tensor(row, dtype=torch.int32, device="cuda") for row in z["inject/s_t"]]
     return m, Trainer(m), (x, sem, ins, n), sel, inj
 
@@ -138,6 +144,27 @@ def test_gradients_vs_reference_f64():
         tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
         torch.cuda.synchronize()
     _check_gradients(m, z, z32, "64x64 B=2 fp32 storage", rerun)
+
+
+@pytest.mark.parametrize("size", [64, 256])
+def test_gradients_with_dropout_vs_reference_f64(size):
+    """The configuration train.py and bench.py actually run: Dropout2d p=.5 (config.py:64) in every decoder level
+    (nn.Dropout2d in `cross`, utils.py:984; F.dropout2d twice per level, utils.py:1104-1110), the reference's recorded
+    keep masks injected.  Covers the per-image channel multipliers in the forward prologues and their backward: a wrong
+    1/keep factor or a mask on the wrong side of a BatchNorm moves every gradient upstream of it."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_%d_drop_f64.npz" % size))
+    z32 = np.load(os.path.join(ROOT, "tests", "golden", "train_%d_drop.npz" % size))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
+    out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+    torch.cuda.synchronize()
+    for i, k in enumerate(("criterion", "ins_ce_loss", "ins_dice_loss")):
+        ref = float(z["scalars/" + k][0])
+        assert abs(float(out["head"][i + 1]) - ref) <= 1e-4 * max(1.0, abs(ref)), k
+    def rerun():
+        tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+        torch.cuda.synchronize()
+    _check_gradients(m, z, z32, "%dx%d B=2 fp32 storage, Dropout2d on" % (size, size), rerun)
 
 
 def test_gradients_256_vs_reference_f64():

@@ -66,7 +66,10 @@ def run_with_gt(z, dtype, training):
     if training:
         P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
              for k, v in P.items()}
-    ctx = R.Ctx(bn_train=training, training=training, capture=True, drop_rate=0.0)
+    # *_drop fixtures: Dropout2d active at the reference's rate, the recorded keep masks injected (oracle/gen_golden.py)
+    masks = {k[len("inject/drop/"):]: torch.from_numpy(z[k]).to(dtype) for k in z.files if k.startswith("inject/drop/")}
+    ctx = R.Ctx(bn_train=training, training=training, capture=True, drop_rate=0.5 if masks else 0.0,
+                drop_masks=masks or None)
     st = R.HeadState()
     pick = (lambda a: torch.topk(a, 3, dim=1).indices[:, 2])
     if training:
@@ -113,6 +116,8 @@ def test_eval_with_gt_matches_reference(golden_dir):
 @pytest.mark.parametrize("case,dtype,tol,gtol", [
     ("train_64_f64", torch.float64, 1e-6, 1e-6),      # fixture stores float32 samples of an f64 run
     ("train_64", torch.float32, 2e-4, None),
+    ("train_64_drop_f64", torch.float64, 1e-6, 1e-6),  # Dropout2d p=.5 active (config.py:64), masks injected
+    ("train_64_drop", torch.float32, 2e-4, None),
 ])
 def test_train_step_matches_reference(golden_dir, case, dtype, tol, gtol):
     z = load(golden_dir, case)
