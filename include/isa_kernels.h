@@ -413,11 +413,45 @@ int isa_collate_targets(const uint8_t* ins, const uint8_t* sem, int32_t n, int32
 /* ---- exact augmentations: the index-permuting part of AlignCollate.__preprocess,
  * code/lib/dataset.py:185-233 - horizontal flip, vertical flip, transpose, rotation by k*90 degrees (preprocess.py:171,
  * 218,286,323; PIL FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM / TRANSPOSE / rotate(expand=True)), in the reference's order.
- * src, dst: uint8 [n,s,s,c] (square images; c = 3 image, 1 semantic map, 32 instance planes), out of place.
+ * src: uint8 [n,h,w,c] (c = 3 image, 1 semantic map, 32 instance planes), out of place; dst: [n,h,w,c], or [n,w,h,c] when
+ * swap_axes != 0 - an op that transposes XOR turns an odd number of quarters exchanges the axes, so one call covers the
+ * images whose ops agree in that parity (any mix on square images).  The reference augments the original, non-square
+ * image (e.g. 2362 x 672) before the resize.
  * ops_dev: int32 [n] on the device, per image: bit0 hflip, bit1 vflip, bit2 transpose, bits 3-4 = quarter turns
  * counter-clockwise (rot_angle / 90).  The random draws stay on the host as in the reference (:186,198,210,222). */
-int isa_d4_augment(const uint8_t* src, uint8_t* dst, int32_t n, int32_t s, int32_t c, const int32_t* ops_dev,
-                   void* stream);
+int isa_d4_augment(const uint8_t* src, uint8_t* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t swap_axes,
+                   const int32_t* ops_dev, void* stream);
+
+/* ---- the non-D4 augmentations the reference ships enabled (settings/CVPPP/training_settings.py:40 ROTATION, :50
+ * CENTER_CUT), AlignCollate.__preprocess code/lib/dataset.py:236-269 ------------------------------------------------
+ * Rotation by `angle` degrees (an integer in [-9, 9], dataset.py:237-239) with expand=True.  The geometry - output size
+ * and the six affine coefficients - is Image.rotate's own Python float arithmetic and stays on the host
+ * (isa_amd.data.rotate_geometry); h, w are the expanded output dims.
+ * nearest (annotation planes and semantic map, preprocess.py:311-327 Image.NEAREST): Pillow's Geometry.c affine_fixed,
+ *   coef = the six 16.16 fixed-point values {a0,a1,a2,a3,a4,a5} (HOST array), zero fill; any channel count.
+ * bilinear (the RGB image, preprocess.py:330-365 rotate_with_random_bg): ImagingGenericTransform + bilinear_filter32RGB
+ *   in IEEE double, (UINT8) truncation; pixels whose sample point lies outside the source take bg (HOST array, c bytes:
+ *   the drawn background colour - white, black, int(mean) or int(median) of the source); c <= 4.
+ * Both are bit-identical to the installed Pillow through oracle/rotate_ref.py (tests/test_oracle_rotate.py). */
+int isa_rotate_nearest_u8(const uint8_t* src, int32_t n, int32_t h0, int32_t w0, int32_t c, uint8_t* dst, int32_t h,
+                          int32_t w, const int32_t* coef_host, void* stream);
+int isa_rotate_bilinear_u8(const uint8_t* src, int32_t n, int32_t h0, int32_t w0, int32_t c, uint8_t* dst, int32_t h,
+                           int32_t w, const double* matrix_host, const uint8_t* bg_host, void* stream);
+/* CenterCut (preprocess.py:239-264, dataset.py:252-269).
+ * cover_rows: single[n,h,w] = 1 where exactly one instance plane covers the pixel (`ins_all == 1`, the candidate
+ *   centres in row-major order), row_counts[n,h] = their number per row - the host picks the drawn candidate from h ints
+ *   and one row of `single` instead of downloading the planes.
+ * plane_sums: sums[n,c] (zeroed by the caller) += the sum of every channel over the window [y0,y0+h) x [x0,x0+w): the
+ *   reference keeps a plane when its window sums to more than 30.
+ * crop_planes: dst[n,h,w,cd] = the window of the channels chan_dev[j] (device int32 [cd]; -1 or out of range = a zero
+ *   plane, NULL = identity): crop, compaction of the surviving planes and the zero planes up to 32 (dataset.py:304-311)
+ *   in one pass; with c = cd = 3 / 1 the image and semantic-map crops. */
+int isa_cover_rows_u8(const uint8_t* planes, int32_t n, int32_t h, int32_t w, int32_t k, uint8_t* single,
+                      int32_t* row_counts, void* stream);
+int isa_plane_sums_u8(const uint8_t* src, int32_t n, int32_t H, int32_t W, int32_t c, int32_t y0, int32_t x0, int32_t h,
+                      int32_t w, int64_t* sums, void* stream);
+int isa_crop_planes_u8(const uint8_t* src, int32_t n, int32_t H, int32_t W, int32_t c, int32_t y0, int32_t x0, uint8_t* dst,
+                       int32_t h, int32_t w, int32_t cd, const int32_t* chan_dev, void* stream);
 
 /* Nearest-neighbour resize of annotation planes: the `ann_resizer` of AlignCollate
  * (code/lib/dataset.py:162,168,293-320 -> utils.py:26-27 -> PIL Image.resize(NEAREST), once per instance plane and

@@ -59,24 +59,186 @@ class SyntheticLoader(object):
             yield x, sem, ins, n
 
 
+def d4_swaps(op):
+    """True when op code `op` exchanges the image axes (transpose XOR an odd number of quarter turns)."""
+    return bool(((op >> 2) ^ (op >> 3)) & 1)
+
+
 def d4_augment(tensors, ops, device="cuda"):
     """The exact augmentations of the reference's collate function (dataset.py:185-233: horizontal / vertical flip,
-    transpose, 90x rotation) on the device, one shared op code per image for all of `tensors` (uint8 [n,s,s,c] or
-    [n,s,s]: RGB image, semantic map, instance planes).  ops: per-image codes, bit0 hflip, bit1 vflip, bit2 transpose,
+    transpose, 90x rotation) on the device, one shared op code per image for all of `tensors` (uint8 [n,h,w,c] or
+    [n,h,w]: RGB image, semantic map, instance planes).  ops: per-image codes, bit0 hflip, bit1 vflip, bit2 transpose,
     bits 3-4 = rot_angle // 90; the random draws stay on the host in the reference's call order (three
-    random.random() < 0.5, one np.random.choice([0, 90, 180, 270]) per image).  Returns new device tensors."""
+    random.random() < 0.5, one np.random.choice([0, 90, 180, 270]) per image).  Non-square images (the reference
+    augments the original image, before the resize): every op of the call must agree on whether it exchanges the axes
+    (d4_swaps), the outputs are [n,w,h,...] then.  Returns new device tensors."""
     from . import lib as L
-    ops_dev = torch.as_tensor(list(ops), dtype=torch.int32).to(device)
+    ops = [int(o) for o in ops]
+    ops_dev = torch.as_tensor(ops, dtype=torch.int32).to(device)
     out = []
     for t in tensors:
-        assert t.dtype == torch.uint8 and t.dim() in (3, 4) and t.shape[1] == t.shape[2], "uint8 [n,s,s(,c)]"
+        assert t.dtype == torch.uint8 and t.dim() in (3, 4), "uint8 [n,h,w(,c)]"
         src = t.to(device).contiguous()
-        dst = torch.empty_like(src)
+        n, h, w = src.shape[:3]
+        swap = d4_swaps(ops[0])
+        assert h == w or all(d4_swaps(o) == swap for o in ops), "ops of one call must agree on exchanging the axes of a non-square image"
+        swap = swap and h != w
+        shape = (n, w, h) + tuple(src.shape[3:]) if swap else tuple(src.shape)
+        dst = torch.empty(shape, dtype=torch.uint8, device=src.device)
         c = 1 if t.dim() == 3 else t.shape[3]
-        L.check(L.lib().isa_d4_augment(L.ptr(src), L.ptr(dst), src.shape[0], src.shape[1], c, L.ptr(ops_dev),
+        L.check(L.lib().isa_d4_augment(L.ptr(src), L.ptr(dst), n, h, w, c, 1 if swap else 0, L.ptr(ops_dev),
                                        L.stream_ptr()), "isa_d4_augment")
         out.append(dst)
     return out
+
+
+# ---- rotation by a small angle and centre cut: the two non-D4 augmentations the reference ships enabled
+# (settings/CVPPP/training_settings.py:40,50; AlignCollate.__preprocess, dataset.py:236-269) -----------------------------
+def rotate_geometry(w, h, angle):
+    """PIL Image.rotate(angle, expand=True)'s own arithmetic (Python floats, Image.py): the affine matrix that maps an
+    output pixel to the source and the expanded output size.  Returns (matrix[6], (nw, nh)), or None when Pillow takes a
+    transpose fast path (angle % 360 in {0, 90, 180, 270}: see d4_augment)."""
+    import math
+    angle = angle % 360.0
+    if angle in (0, 90, 180, 270):
+        return None
+    cx, cy = w / 2, h / 2
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+
+    def tf(x, y):
+        return m[0] * x + m[1] * y + m[2], m[3] * x + m[4] * y + m[5]
+
+    m[2], m[5] = tf(-cx, -cy)
+    m[2] += cx
+    m[5] += cy
+    xs, ys = zip(*(tf(x, y) for x, y in ((0, 0), (w, 0), (w, h), (0, h))))
+    nw = math.ceil(max(xs)) - math.floor(min(xs))
+    nh = math.ceil(max(ys)) - math.floor(min(ys))
+    m[2], m[5] = tf(-(nw - w) / 2.0, -(nh - h) / 2.0)
+    return m, (nw, nh)
+
+
+def _fixed_coeffs(m):
+    """Geometry.c affine_fixed: FIX(v) = floor(v * 65536 + 0.5), the half-pixel centre folded into the offsets."""
+    import math
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
+
+
+def rotate_nearest(tensors, angle, device="cuda"):
+    """The reference's annotation rotator (dataset.py:142,243-249: Image.rotate(angle, NEAREST, expand=True) per instance
+    plane and for the semantic map) on the device for uint8 [n,h,w,c] tensors sharing one angle; bit-identical to Pillow."""
+    import ctypes as C
+    from . import lib as L
+    out = []
+    for t in tensors:
+        src = t.to(device).contiguous()
+        assert src.dtype == torch.uint8 and src.dim() == 4
+        n, h, w, c = src.shape
+        g = rotate_geometry(w, h, angle)
+        if g is None:                       # Pillow's transpose fast paths: a quarter-turn op of d4_augment (0 = copy)
+            q = int(angle % 360) // 90
+            out.append(src.clone() if q == 0 else d4_augment([src], [q << 3] * n, device)[0])
+            continue
+        m, (nw, nh) = g
+        coef = (C.c_int32 * 6)(*_fixed_coeffs(m))
+        dst = torch.empty((n, nh, nw, c), dtype=torch.uint8, device=src.device)
+        L.check(L.lib().isa_rotate_nearest_u8(L.ptr(src), n, h, w, c, L.ptr(dst), nh, nw, coef, L.stream_ptr()),
+                "isa_rotate_nearest_u8")
+        out.append(dst)
+    return out
+
+
+def background_colour(rgb_host, key):
+    """preprocess.py:349-362: the four backgrounds of rotate_with_random_bg - 0 white, 1 black, 2 int(mean), 3 int(median)
+    per channel of the source image (host numpy array [h,w,3]; the reference computes them on the host as well)."""
+    import numpy as np
+    if key == 0:
+        return (255, 255, 255)
+    if key == 1:
+        return (0, 0, 0)
+    if key == 2:
+        return tuple(int(v) for v in rgb_host.mean((0, 1)))
+    return tuple(int(v) for v in np.median(rgb_host, (0, 1)))
+
+
+def rotate_image(rgb, angle, bg, device="cuda"):
+    """The reference's image rotator (dataset.py:140,241 -> preprocess.py:330-365 rotate_with_random_bg: RGBA, BILINEAR,
+    expand, composite over the drawn background `bg`) on the device: uint8 [n,h,w,3] -> [n,nh,nw,3], bit-identical to
+    Pillow."""
+    import ctypes as C
+    from . import lib as L
+    src = rgb.to(device).contiguous()
+    assert src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] <= 4
+    n, h, w, c = src.shape
+    g = rotate_geometry(w, h, angle)
+    if g is None:
+        q = int(angle % 360) // 90
+        return src.clone() if q == 0 else d4_augment([src], [q << 3] * n, device)[0]
+    m, (nw, nh) = g
+    mat = (C.c_double * 6)(*m)
+    bgc = (C.c_uint8 * 4)(*([int(v) for v in bg] + [255] * (4 - len(bg))))
+    dst = torch.empty((n, nh, nw, c), dtype=torch.uint8, device=src.device)
+    L.check(L.lib().isa_rotate_bilinear_u8(L.ptr(src), n, h, w, c, L.ptr(dst), nh, nw, mat, bgc, L.stream_ptr()),
+            "isa_rotate_bilinear_u8")
+    return dst
+
+
+def center_cut_window(H, W, center, h, w):
+    """preprocess.py:239-264 CenterCut: the window (y0, x0, height, width) it takes from an H x W array around `center`
+    for an h x w output (it doubles both and clamps to the image)."""
+    h, w = 2 * h, 2 * w
+    if center[0] - h // 2 < 0:
+        y0 = 0
+    elif center[0] + h // 2 > H:
+        y0 = max(0, H - h)
+    else:
+        y0 = center[0] - h // 2
+    if center[1] - w // 2 < 0:
+        x0 = 0
+    elif center[1] + w // 2 > W:
+        x0 = max(0, W - w)
+    else:
+        x0 = center[1] - w // 2
+    return int(y0), int(x0), min(H, y0 + min(H, h)) - int(y0), min(W, x0 + min(W, w)) - int(x0)
+
+
+def center_cut(rgb, sem, planes, n_objects, draw, out_h, out_w, max_planes=32, device="cuda"):
+    """dataset.py:252-269 on the device for ONE image: rgb uint8 [1,H,W,3], sem uint8 [1,H,W,1], planes uint8 [1,H,W,K]
+    (the first n_objects are real).  `draw(count)` returns the reference's np.random.choice(count) - the index of the
+    chosen centre in the row-major list of pixels covered by exactly one plane.  Returns (rgb, sem, planes [1,h',w',
+    max_planes] with the surviving planes first, n_objects') - the has-object filter (window sum > 30) drops planes."""
+    from . import lib as L
+    lib, st = L.lib(), L.stream_ptr()
+    _, H, W, K = planes.shape
+    single = torch.empty((1, H, W), dtype=torch.uint8, device=device)
+    rows = torch.empty((1, H), dtype=torch.int32, device=device)
+    real = planes if n_objects == K else planes[..., :n_objects].contiguous()
+    L.check(lib.isa_cover_rows_u8(L.ptr(real), 1, H, W, n_objects, L.ptr(single), L.ptr(rows), st), "isa_cover_rows_u8")
+    counts = rows[0].cpu().numpy().astype("int64")
+    total = int(counts.sum())
+    assert total > 0, "no pixel is covered by exactly one instance (the reference raises here too)"
+    pick = int(draw(total))
+    cum = counts.cumsum()
+    r = int((cum > pick).argmax())
+    j = pick - int(cum[r] - counts[r])
+    cols = single[0, r].cpu().numpy().nonzero()[0]
+    center = (r, int(cols[j]))
+    y0, x0, hh, ww = center_cut_window(H, W, center, out_h, out_w)
+    sums = torch.zeros((1, n_objects), dtype=torch.int64, device=device)
+    L.check(lib.isa_plane_sums_u8(L.ptr(real), 1, H, W, n_objects, y0, x0, hh, ww, L.ptr(sums), st), "isa_plane_sums_u8")
+    keep = [i for i, v in enumerate(sums[0].cpu().tolist()) if v > 30]
+    chan = torch.tensor(keep + [-1] * (max_planes - len(keep)), dtype=torch.int32, device=device)
+    p2 = torch.empty((1, hh, ww, max_planes), dtype=torch.uint8, device=device)
+    L.check(lib.isa_crop_planes_u8(L.ptr(real), 1, H, W, n_objects, y0, x0, L.ptr(p2), hh, ww, max_planes, L.ptr(chan), st),
+            "isa_crop_planes_u8")
+    r2 = torch.empty((1, hh, ww, rgb.shape[3]), dtype=torch.uint8, device=device)
+    L.check(lib.isa_crop_planes_u8(L.ptr(rgb), 1, H, W, rgb.shape[3], y0, x0, L.ptr(r2), hh, ww, rgb.shape[3], None, st),
+            "isa_crop_planes_u8")
+    s2 = torch.empty((1, hh, ww, 1), dtype=torch.uint8, device=device)
+    L.check(lib.isa_crop_planes_u8(L.ptr(sem), 1, H, W, 1, y0, x0, L.ptr(s2), hh, ww, 1, None, st), "isa_crop_planes_u8")
+    return r2, s2, p2, len(keep)
 
 
 _RESIZE_WS = {}
@@ -141,7 +303,7 @@ def device_collate_targets(planes, sem, ops=None, size=256, device="cuda"):
     """The annotation side of the reference's collate function on the device, in its order (dataset.py:185-233 exact
     augmentations at the source resolution, :293-320 nearest resize, :349-379 int64 planes + one-hot):
     planes uint8 [n,h0,w0,K] (zero planes already appended up to K = 32, :305-311), sem uint8 [n,h0,w0], ops = per-image
-    D4 op codes or None.  Square sources are required when an op transposes.  Returns (sem_onehot int64 [n,2,size,size],
+    D4 op codes or None (on non-square sources the ops of one call must agree on exchanging the axes).  Returns (sem_onehot int64 [n,2,size,size],
     ins int64 [n,K,size,size]) on the device; three launches instead of ~70 PIL calls per image."""
     from . import lib as L
     planes, sem = planes.to(device).contiguous(), sem.to(device).contiguous()
@@ -149,6 +311,7 @@ def device_collate_targets(planes, sem, ops=None, size=256, device="cuda"):
     sem4 = sem.reshape(n, h0, w0, 1)
     if ops is not None:
         planes, sem4 = d4_augment([planes, sem4], ops, device)
+        n, h0, w0, k = planes.shape
     st = L.stream_ptr()
     p2 = torch.empty((n, size, size, k), dtype=torch.uint8, device=device)
     s2 = torch.empty((n, size, size, 1), dtype=torch.uint8, device=device)

@@ -508,6 +508,8 @@ class Engine:
         self._deferring = False
         self.defer_fold = os.environ.get("ISA_DEFER_FOLD", "1") != "0"    # 0: immediate folds (A/B, single stream only)
         self.bn_repeat = 1             # see repeated()
+        self.arena_cache = int(os.environ.get("ISA_ARENA_CACHE", "4"))
+        self._eval_bn_ready: Dict[str, tuple] = {}    # layer -> (event after its first-fill finalize, stream id it ran on)
 
     # ------------------------------------------------------------------ step lifecycle
     def begin(self, bn_train: bool, record: bool, key=None):
@@ -515,9 +517,15 @@ class Engine:
         arena, so an eval forward between two replays of a captured training graph cannot free or reshape the
         buffers that graph points to (Arena.frozen turns a diverging sequence into an error)."""
         akey = (bool(bn_train), bool(record), key)
-        arena = self.arenas.get(akey)
+        arena = self.arenas.pop(akey, None)
         if arena is None:
-            arena = self.arenas[akey] = Arena(self.device)
+            arena = Arena(self.device)
+        self.arenas[akey] = arena                  # dict order = least recently used first
+        # Every configuration pins a full activation set; arenas of captured graphs (frozen) must stay, the others are
+        # bounded: the least recently used un-captured ones are dropped beyond ISA_ARENA_CACHE (default 4) of them
+        loose = [k for k, a in self.arenas.items() if not a.frozen and k != akey and k is not None]
+        for k in loose[:max(0, len(loose) - self.arena_cache)]:
+            del self.arenas[k]
         self.arena = arena
         arena.reset()
         if POISON:
@@ -574,7 +582,12 @@ class Engine:
 
     def sync(self, src, dst):
         """Forward edge: everything issued so far on stream `src` happens before what follows on `dst`.  Recorded on
-        the tape, so the backward pass replays the edge reversed (the gradients flow dst -> src)."""
+        the tape, so the backward pass replays the edge reversed (the gradients flow dst -> src).
+        One end must be the step's own stream: ROCm 7.2's hipStreamEndCapture dereferences a null node when a captured
+        graph holds side -> side edges (scripts/graph_probe.py) - a process-killing segfault, so it is an error here."""
+        if src != 0 and dst != 0 and src != dst:
+            raise RuntimeError("Engine.sync(%d, %d): stream edges must have the step's own stream (0) at one end - "
+                               "side-to-side edges crash hipGraph capture on ROCm 7.2" % (src, dst))
         self._wait(src, dst)
         if self.record:
             self.tape.mark_sync(src, dst)
@@ -585,12 +598,20 @@ class Engine:
         q = self.bn_running_queue
         if not q:
             return
-        arr = (L.IsaBnUpd * len(q))()
         P = self.params
-        for i, (stats, count, pre, c) in enumerate(q):
-            arr[i] = L.IsaBnUpd(stats.data_ptr(), P.ptr(pre + ".running_mean").value, P.ptr(pre + ".running_var").value,
-                                count, c)
-        L.check(self.lib.isa_bn_running_update(arr, len(q), self.BN_MOMENTUM, self.st()), "isa_bn_running_update")
+        # isa_bn_running_update runs one workgroup per descriptor, concurrently: two updates of the SAME layer (three or
+        # more decoder iterations on side streams) must not share a launch - the queue is cut into runs of distinct layers
+        runs, seen = [[]], set()
+        for ent in q:
+            if ent[2] in seen:
+                runs.append([]); seen = set()
+            seen.add(ent[2]); runs[-1].append(ent)
+        for run in runs:
+            arr = (L.IsaBnUpd * len(run))()
+            for i, (stats, count, pre, c) in enumerate(run):
+                arr[i] = L.IsaBnUpd(stats.data_ptr(), P.ptr(pre + ".running_mean").value, P.ptr(pre + ".running_var").value,
+                                    count, c)
+            L.check(self.lib.isa_bn_running_update(arr, len(run), self.BN_MOMENTUM, self.st()), "isa_bn_running_update")
         self.bn_running_queue = []
 
     def _finalize_train(self, stats, count, pre, c, scale, shift, mean, invstd, groups=1):
@@ -610,6 +631,19 @@ class Engine:
     def defer_handle(self):
         """isa_slab_arena* for the weight-gradient entry points while a backward pass runs, else NULL."""
         return self.slab if (self._deferring and self.defer_fold) else None
+
+    def _eval_bn_filled(self, pre):
+        """The first-fill finalize of an eval-mode BN constant set was just queued on the current stream: remember an event
+        so that a consumer on ANOTHER stream (the decoder iterations share weights and may meet the cache entry before
+        that finalize ran) waits for it instead of reading unwritten constants."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._eval_bn_ready[pre] = (ev, self.cur)
+
+    def _eval_bn_wait(self, pre):
+        ent = self._eval_bn_ready.get(pre)
+        if ent is not None and ent[1] != self.cur and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_event(ent[0])
 
     def refresh_eval_bn(self):
         """Recompute the cached eval-mode BN constants in place (same buffers: captured graphs keep reading them)."""
@@ -698,6 +732,9 @@ class Engine:
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(cached[0]), L.ptr(cached[1]),
                                              L.ptr(cached[2]), L.ptr(cached[3]), c, 1, 1, self.st()), "isa_bn_finalize")
+            self._eval_bn_filled(pre)
+        else:
+            self._eval_bn_wait(pre)
         return cached
 
     def conv_bn_eval(self, x: Act, wname, out: Act, bn_pre, act, res: Optional[Act] = None, taps=1):
@@ -919,6 +956,9 @@ class Engine:
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
                                              L.ptr(invstd), c, 1, 1, self.st()), "isa_bn_finalize")
+            self._eval_bn_filled(pre)
+        else:
+            self._eval_bn_wait(pre)
         lazy = raw.with_pro(Pro(scale, shift, act))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
@@ -993,6 +1033,9 @@ class Engine:
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
                                              self.BN_MOMENTUM, self.BN_EPS, L.ptr(scale), L.ptr(shift), L.ptr(mean),
                                              L.ptr(invstd), c, 1, 1, self.st()), "isa_bn_finalize")
+            self._eval_bn_filled(pre)
+        else:
+            self._eval_bn_wait(pre)
         lazy = raw.with_pro(Pro(scale, shift, act, bscale))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)

@@ -72,7 +72,12 @@ SIGNATURES = {
     "isa_slab_arena_begin": [VP],
     "isa_slab_arena_flush": [VP, VP, VP, VP],
     "isa_bn_running_update": [C.POINTER(IsaBnUpd), I32, F, VP],
-    "isa_d4_augment": [VP, VP, I32, I32, I32, VP, VP],
+    "isa_d4_augment": [VP, VP, I32, I32, I32, I32, I32, VP, VP],
+    "isa_rotate_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP, VP],
+    "isa_rotate_bilinear_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP, VP, VP],
+    "isa_cover_rows_u8": [VP, I32, I32, I32, I32, VP, VP, VP],
+    "isa_plane_sums_u8": [VP, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP],
+    "isa_crop_planes_u8": [VP, I32, I32, I32, I32, I32, I32, VP, I32, I32, I32, VP, VP],
     "isa_resize_nearest_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP],
     "isa_resize_bilinear_u8": [VP, I32, I32, I32, I32, VP, I32, I32, VP, I64, VP],
     "isa_collate_targets": [VP, VP, I32, I32, I32, I32, VP, VP, VP],

@@ -115,12 +115,18 @@ class Model(object):
             # every rank validates the same model: average the per-rank running estimates first
             parallel.sync_buffers(self.model.store, self.model.head.baseline if self.use_instance_segmentation else None,
                                   self.world)
+            if self.world > 1:
+                self.model.engine.eval_bn_stale = True      # the running statistics were rewritten: cached eval constants are old
             va = [self.__minibatch(b, 'test') for b in test_loader]
-            mean = lambda rows, k: float(torch.stack([r[k].float() for r in rows]).mean())
+            # an empty loader (a validation set smaller than one batch per rank under a dropping sampler) must not take the
+            # epoch down on every rank: its mean is NaN and the plateau scheduler sees the training cost instead
+            mean = lambda rows, k: float(torch.stack([r[k].float() for r in rows]).mean()) if rows else float("nan")
             key = 'ins_dice_loss' if self.use_instance_segmentation else 'Dice Cost'
             # rank-averaged costs: the plateau scheduler must take the same decision on every rank
             train_cost = parallel.mean_over_ranks(mean(tr, key), self.world)
             val_cost = parallel.mean_over_ranks(mean(va, key), self.world)
+            if val_cost != val_cost:
+                val_cost = train_cost
             if main:
                 print('Epoch : [{}/{}]  train {} {:.5f} | val {:.5f}'.format(epoch, n_epochs, key, train_cost, val_cost))
             self.__plateau_step(val_cost)

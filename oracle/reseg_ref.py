@@ -50,12 +50,21 @@ class Ctx:
     # name -> [B,C] multiplicative channel masks (already scaled by 1/(1-p)); None => identity
     drop_masks: Optional[Dict[str, torch.Tensor]] = None
     capture: bool = False
+    # optional storage-rounding emulation (tests/bf16_grad_floor.py): applied to every raw convolution output ahead of
+    # its BatchNorm and to every block output, straight-through in the backward pass - the reference's arithmetic with
+    # activations STORED in a narrower type.  None (default) = the reference's own arithmetic.
+    storage_round: Optional[object] = None
     taps: Dict[str, torch.Tensor] = field(default_factory=dict)
     new_buffers: Dict[str, torch.Tensor] = field(default_factory=dict)
 
     def tap(self, name, t):
         if self.capture:
             self.taps[name] = t
+
+    def q(self, x):
+        if self.storage_round is None:
+            return x
+        return x + (self.storage_round(x.detach()) - x.detach())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -64,6 +73,7 @@ class Ctx:
 def batchnorm(P, pre, x, ctx: Ctx):
     """nn.BatchNorm2d semantics (train: biased batch var, running update with unbiased var)."""
     w, b = P[pre + ".weight"], P[pre + ".bias"]
+    x = ctx.q(x)
     if ctx.bn_train:
         dims = (0, 2, 3)
         n = x.numel() // x.shape[1]
@@ -94,7 +104,7 @@ def block_v1(P, pre, x, ctx):
     y = relu6(batchnorm(P, pre + ".conv.1", y, ctx))
     y = F.conv2d(y, P[pre + ".conv.3.weight"])
     y = batchnorm(P, pre + ".conv.4", y, ctx)
-    return x + y if y.shape[1] == cin else y
+    return ctx.q(x + y if y.shape[1] == cin else y)
 
 
 def block_ir(P, pre, x, ctx):
@@ -106,7 +116,7 @@ def block_ir(P, pre, x, ctx):
     y = relu6(batchnorm(P, pre + ".conv.4", y, ctx))
     y = F.conv2d(y, P[pre + ".conv.6.weight"])
     y = batchnorm(P, pre + ".conv.7", y, ctx)
-    return x + y if y.shape[1] == cin else y
+    return ctx.q(x + y if y.shape[1] == cin else y)
 
 
 def dropout2d(x, name, ctx: Ctx, active: bool):

@@ -17,7 +17,7 @@ o = torch.tensor(ops, dtype=torch.int32, device="cuda")
 for name, c in (("instance planes", 32), ("RGB image", 3), ("semantic map", 1)):
     x = rng.integers(0, 2, (B, S, S, c), dtype=np.uint8)
     d = torch.from_numpy(x).cuda(); out = torch.empty_like(d)
-    f = lambda: L.lib().isa_d4_augment(L.ptr(d), L.ptr(out), B, S, c, L.ptr(o), L.stream_ptr())
+    f = lambda: L.lib().isa_d4_augment(L.ptr(d), L.ptr(out), B, S, S, c, 0, L.ptr(o), L.stream_ptr())
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): f()

@@ -25,7 +25,7 @@ def run(L, x, ops):
     out = torch.full_like(d, 201)
     o = torch.tensor(ops, dtype=torch.int32, device="cuda")
     n, s, _, c = x.shape
-    assert L.lib().isa_d4_augment(L.ptr(d), L.ptr(out), n, s, c, L.ptr(o), L.stream_ptr()) == 0
+    assert L.lib().isa_d4_augment(L.ptr(d), L.ptr(out), n, s, s, c, 0, L.ptr(o), L.stream_ptr()) == 0
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -64,10 +64,10 @@ def test_invalid_arguments():
     u = torch.zeros(64, dtype=torch.uint8, device="cuda")
     o = torch.zeros(4, dtype=torch.int32, device="cuda")
     f = L.lib().isa_d4_augment
-    assert f(L.ptr(t), L.ptr(t), 1, 4, 4, L.ptr(o), L.stream_ptr()) != 0          # in place
-    assert f(L.ptr(t), L.ptr(u), 1, 4, 4, None, L.stream_ptr()) != 0
-    assert f(L.ptr(t), L.ptr(u), 0, 4, 4, L.ptr(o), L.stream_ptr()) != 0
-    assert f(None, L.ptr(u), 1, 4, 4, L.ptr(o), L.stream_ptr()) != 0
+    assert f(L.ptr(t), L.ptr(t), 1, 4, 4, 4, 0, L.ptr(o), L.stream_ptr()) != 0          # in place
+    assert f(L.ptr(t), L.ptr(u), 1, 4, 4, 4, 0, None, L.stream_ptr()) != 0
+    assert f(L.ptr(t), L.ptr(u), 0, 4, 4, 4, 0, L.ptr(o), L.stream_ptr()) != 0
+    assert f(None, L.ptr(u), 1, 4, 4, 4, 0, L.ptr(o), L.stream_ptr()) != 0
 
 
 def test_host_helper_shares_one_op_per_image():

@@ -422,3 +422,30 @@ def test_slab_arena_abi_contract():
         else:
             assert eng.fold_stats[0] == 1, eng.fold_stats
             assert rel(2 * eng.params.gview("w"), ref) < 1e-5
+
+
+def test_side_to_side_stream_edges_are_refused():
+    """hipStreamEndCapture segfaults on ROCm 7.2 when a captured graph has side -> side edges (scripts/graph_probe.py;
+    it killed a test process in round 2): Engine.sync turns the topology into an exception before anything is issued."""
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    eng = make_engine(Engine, ParamStore, [("w", (8, 8, 1, 1))], dict(w=rand(8, 8, 1, 1)), torch.float32)
+    eng.sync(0, 1); eng.sync(1, 0); eng.sync(2, 2)          # origin at one end / no edge at all: fine
+    with pytest.raises(RuntimeError, match="side-to-side"):
+        eng.sync(1, 2)
+
+
+def test_uncaptured_arenas_are_bounded():
+    """Every configuration key owns an arena (a full activation set); the un-captured ones are an LRU of ISA_ARENA_CACHE
+    entries, frozen ones (a captured hipGraph points into them) are never dropped."""
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    eng = make_engine(Engine, ParamStore, [("w", (8, 8, 1, 1))], dict(w=rand(8, 8, 1, 1)), torch.float32)
+    eng.begin(False, False, key="graph")
+    eng.new_act(1, 4, 4, 8)
+    eng.freeze_arena()
+    for i in range(12):
+        eng.begin(False, False, key=("shape", i))
+        eng.new_act(1, 4, 4, 8)
+    keys = [k for k in eng.arenas if k is not None]
+    assert (False, False, "graph") in keys and (False, False, ("shape", 11)) in keys
+    assert len([k for k in keys if not eng.arenas[k].frozen]) <= eng.arena_cache + 1
+    assert (False, False, ("shape", 0)) not in keys

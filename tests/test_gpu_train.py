@@ -439,8 +439,8 @@ def test_learning_rate_change_reaches_the_captured_graph():
     assert float((d_half - e_half).norm() / e_half.norm()) < 5e-2
 
 
-@pytest.mark.parametrize("streams", [2, 3])
-def test_concurrent_streams_match_the_sequential_pass(streams):
+@pytest.mark.parametrize("batched,streams", [(True, 2), (False, 2), (False, 3)])
+def test_concurrent_streams_match_the_sequential_pass(batched, streams):
     """The decoder iterations (and their cross chains) run on separate HIP streams; what the reference's sequential
     loop (attenet2.py:384-399) guaranteed implicitly is restored explicitly: ordered BatchNorm running-statistics
     updates (isa_bn_running_update), per-stream gradients of the shared backbone features merged after the join,
@@ -454,6 +454,7 @@ def test_concurrent_streams_match_the_sequential_pass(streams):
         m.load_state_dict(state0)
         m.head.baseline = None
         m.head.streams = ns
+        m.head.batch_iters = batched      # batched: the cross chain beside the level chain; else the iterations side by side
         cap = {}
         out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj, capture=cap)
         torch.cuda.synchronize()
@@ -480,3 +481,133 @@ def test_concurrent_streams_match_the_sequential_pass(streams):
     for u, v in zip(h1, hN):
         assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
     assert abs(b1 - bN) <= 1e-6 * max(1.0, abs(b1))
+
+
+def test_batched_iterations_match_the_per_iteration_pass():
+    """ISA_BATCH_ITERS (default on): the decoder iterations as ONE pass over max_iter * B images with a BatchNorm statistic
+    group per iteration, the iteration-independent cross block evaluated once.  Must equal the one-pass-per-iteration
+    path (the reference's own loop structure, attenet2.py:384-399) in every captured activation, gradient, running
+    statistic, num_batches_tracked, loss scalar and the REINFORCE baseline - with Dropout2d active (masks injected)."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_64_drop_f64.npz"))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.float32)
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run(batched):
+        m.load_state_dict(state0)
+        m.head.baseline = None
+        m.head.batch_iters = batched
+        m.head.streams = 1
+        cap = {}
+        out = tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj, capture=cap)
+        torch.cuda.synchronize()
+        acts = {k: v.nchw().clone() for k, v in cap.items() if k.startswith("it")}
+        sd = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        return m.store.grad.double().clone(), acts, sd, [float(v) for v in out["head"][1:]], float(m.head.baseline)
+
+    g1, a1, s1, h1, b1 = run(False)
+    g1b = run(False)[0]
+    gN, aN, sN, hN, bN = run(True)
+    noise = float((g1 - g1b).norm() / g1.norm())
+    diff = float((g1 - gN).norm() / g1.norm())
+    assert diff <= max(5 * noise, 1e-2), (noise, diff)
+    assert float(torch.nn.functional.cosine_similarity(g1, gN, dim=0)) > 0.9999
+    assert set(a1) == set(aN) and len(a1) == 20
+    for k in a1:
+        assert float((a1[k] - aN[k]).abs().max()) <= 1e-4 * max(1.0, float(a1[k].abs().max())), k
+    for k in s1:
+        if "num_batches" in k:
+            assert int(s1[k]) == int(sN[k]), k
+        else:
+            assert float((s1[k] - sN[k]).abs().max()) <= 1e-5 * max(1.0, float(s1[k].abs().max())), k
+    for u, v in zip(h1, hN):
+        assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
+    assert abs(b1 - bN) <= 1e-6 * max(1.0, abs(b1))
+
+
+def _family(name):
+    if name.startswith("base."):
+        return "backbone"
+    if name.startswith("decoder.bone."):
+        return "decoder"
+    return "stems+heads"
+
+
+def test_backbone_gradients_tight_vs_oracle_f64():
+    """A tight bound for the backbone kernels on their own.  In the full step every backbone gradient inherits the
+    threshold flips of the ten decoder levels behind it (see _check_gradients), which is why its bound there is loose.
+    Here the instance head is off (ReSeg(2, use_instance_seg=False)): the loss is the trainer's semantic CE + Dice
+    (model.py:255-269), the backward pass runs only the backbone and the semantic head, and the CPU oracle (pinned to the
+    reference by tests/test_oracle_golden.py) supplies float64 gradients for the same weights and batch."""
+    ReSeg, Trainer = need_gpu()
+    x, sem, ins, n = R.synth_batch(2, 64, 64, seed=1)
+    sd = R.synth_state_dict(23, False)
+    m = ReSeg(2, False, dtype=torch.float32)
+    m.load_state_dict(sd)
+    m.train()
+    tr = Trainer(m)
+    out = tr.forward_backward(x, sem, ins, n)
+    torch.cuda.synchronize()
+    P = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+         for k, v in sd.items()}
+    ref = R.reseg_forward(P, x.double(), sem, use_instance_seg=False, ctx=R.Ctx(bn_train=True, training=True))
+    ce, dice = R.sem_losses(ref["sem_out"], sem)
+    assert abs(float(out["sem"][0]) - float(ce)) < 1e-4 and abs(float(out["sem"][1]) - float(dice)) < 1e-4
+    (ce + dice).backward()
+    errs = {}
+    gmax = max(float(v.grad.norm()) for v in P.values() if getattr(v, "grad", None) is not None)
+    for k, v in P.items():
+        if getattr(v, "grad", None) is None or float(v.grad.norm()) <= 1e-6 * gmax:
+            continue
+        g = m.store.gview(k).double().cpu()
+        errs[k] = float((g - v.grad).norm() / v.grad.norm())
+    assert len(errs) > 100
+    worst = max(errs, key=errs.get)
+    med = float(np.median(list(errs.values())))
+    print("backbone-only step, fp32 storage vs float64 oracle: %d tensors, worst rel-L2 %.2e (%s), median %.2e"
+          % (len(errs), errs[worst], worst, med))
+    # measured on MI355X: worst 1.5e-6, median 1.0e-6 (no decoder behind the backbone, no threshold flips at this size)
+    assert errs[worst] <= 1e-4 and med <= 1e-5, (worst, errs[worst], med)
+
+
+def test_bf16_gradients_256_vs_reference_f64():
+    """The TIMED configuration's backward pass (bf16 storage, 256x256, Dropout2d on) against the reference's own float64
+    run, tensor by tensor: relative L2 over the fixture's samples per family, and the cosine between the two gradients
+    over all stored samples.
+    The bounds come from a measured floor: tests/bf16_grad_floor.py runs the float64 oracle (= the reference's arithmetic)
+    on this fixture with nothing changed but bf16 rounding of the STORED activations (raw conv outputs, block outputs)
+    and gets, against its own unrounded gradient: cosine 0.976; relative L2 median / p90 per family: backbone 0.40 / 0.52,
+    decoder 0.30 / 0.58, stems+heads 0.10 / 0.22 - tiny-batch BatchNorm, ReLU6 thresholds and ten decoder levels in
+    series amplify a 2^-9 rounding that far, in any implementation.  The HIP path measures cosine 0.961 and 0.48 / 0.65,
+    0.35 / 0.70, 0.10 / 0.32 (also rounds the gradient tensors and the MFMA operands); bounds = 1.75 x that floor.  What
+    this catches is a systematic error - a sign, a missing 1/keep, a mask on the wrong side of a BatchNorm - which moves
+    the cosine by tenths; what it cannot do is rank two correct bf16 implementations."""
+    ReSeg, Trainer = need_gpu()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_256_drop_f64.npz"))
+    m, tr, batch, sel, inj = setup(ReSeg, Trainer, z, torch.bfloat16)
+    tr.forward_backward(*batch, selected_idx=sel, injected_s_t=inj)
+    torch.cuda.synchronize()
+    names = sorted(set(k.split("/")[1] for k in z.files if k.startswith("grad/")))
+    gmax = max(float(np.sqrt(z["grad/%s/sums" % k][2])) for k in names)
+    fam, dots = {}, [0.0, 0.0, 0.0]
+    for k in names:
+        if float(np.sqrt(z["grad/%s/sums" % k][2])) <= 1e-6 * gmax:
+            continue
+        g = m.store.gview(k).cpu().numpy().astype(np.float64).reshape(-1)
+        ref = _grad_samples(z, k)
+        mine = g if ref.size == g.size else g[::G.subsample_stride(g.size, 512)]
+        fam.setdefault(_family(k), []).append(float(np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30)))
+        dots[0] += float(mine @ ref); dots[1] += float(mine @ mine); dots[2] += float(ref @ ref)
+    cos = dots[0] / np.sqrt(dots[1] * dots[2])
+    stats = {f: (float(np.median(v)), float(np.percentile(v, 90)), float(np.max(v))) for f, v in fam.items()}
+    print("bf16 gradients vs the reference's float64 run at 256x256 (Dropout2d on): cosine %.5f; per family "
+          "median / p90 / max relative L2: %s" % (cos, {f: "%.3f / %.3f / %.3f" % s for f, s in stats.items()}))
+    assert cos >= BF16_GRAD_COS, cos
+    for f, (med, p90, mx) in stats.items():
+        assert med <= BF16_GRAD_MEDIAN[f] and p90 <= BF16_GRAD_P90[f], (f, med, p90, mx)
+
+
+# 1.75 x the bf16-storage floor of the reference's own arithmetic (tests/bf16_grad_floor.py 256; see the docstring)
+BF16_GRAD_COS = 0.92
+BF16_GRAD_MEDIAN = {"backbone": 0.70, "stems+heads": 0.18, "decoder": 0.52}
+BF16_GRAD_P90 = {"backbone": 0.92, "stems+heads": 0.385, "decoder": 1.02}

@@ -105,3 +105,37 @@ def test_fit_from_records(tmp_path):
     m.fit('Multi', 0.5, 1.5, 2, 1.0, 0.001, 10.0, 0.5, 25, False, 'Adadelta', True, 2, None, tr, te, out, False)
     assert [f for f in os.listdir(out) if f.endswith(".pth")]
     assert torch.isfinite(m.model.store.flat).all()
+
+
+def test_rank_shards_have_equal_step_counts_and_keep_short_batches():
+    """len(ds) % world != 0 must not give one rank a step more than the others (it would wait in its gradient
+    all-reduce forever), and a validation set smaller than world * batch must still yield a batch on every rank.  The
+    reference drops nothing: a short last batch is filled by repeating its first image (dataset.py:330-333)."""
+    import isa_amd  # noqa: F401
+    from isa_amd.records import RecordLoader
+
+    class DS(object):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for n, world, bs in ((195, 8, 1), (49, 8, 8), (7, 2, 4), (16, 4, 2), (5, 1, 2)):
+        shards = []
+        for rank in range(world):
+            for mode in ('training', 'test'):
+                ld = RecordLoader(DS(n), bs, mode=mode, seed=3, rank=rank, world=world, device='cpu')
+                ld.epoch = 1
+                idx = ld.indices()
+                shards.append((mode, len(idx), len(ld)))
+                assert len(ld) >= 1
+                if mode == 'test':
+                    assert sorted(set(idx)) == sorted(set(range(n)[rank::world]) | set(idx))     # own slice is covered
+        assert len(set(shards[0::2])) == 1 and len(set(shards[1::2])) == 1, (n, world, bs, shards)
+        # every sample is seen by some rank
+        seen = set()
+        for rank in range(world):
+            ld = RecordLoader(DS(n), bs, mode='test', rank=rank, world=world, device='cpu')
+            seen |= set(ld.indices())
+        assert seen == set(range(n))
