@@ -216,6 +216,7 @@ def main():
                 "avg_launch_us": round(tot_ms * 1e3 / calls, 2),
                 "alg_bytes_per_launch": int(nbytes / calls),
                 "step_frac": round(value / world * step_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                "launches_per_step_all": sum(v[0] for v in prof.values()),
                 "families_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]},
             }
         # ---- CPU baseline: the oracle (port of the reference path) on a bounded sample ----------
@@ -229,10 +230,11 @@ def main():
             import reseg_ref as R
             torch.set_num_threads(max(1, min(ncpu, 16)))      # the GPU box gives one GPU a 16-core share
             log("cpu baseline on %d threads" % torch.get_num_threads())
-            # bounded sample: the oracle's train step costs ~3.5 s per image on 16 host threads, so the benchmark batch
-            # (16 images) would take a minute per repetition; bs=4 keeps the default run within minutes.  The per-image
-            # CPU rate is flat in the batch size (reference itself, profiles/r02_reference_cpu_timing.json: bs=4 vs bs=8)
-            cb = 4 if workload != "infer" else 16
+            # bounded sample: the oracle's train step costs ~2 s per image on 16 host threads, so the benchmark batch
+            # (16 images) would take half a minute per repetition; bs=2 and at least 5 repetitions (median) keep the
+            # default run within minutes and the number stable.  The per-image CPU rate is flat in the batch size (the
+            # reference itself, profiles/r02_reference_cpu_timing.json: bs=4 vs bs=8)
+            cb = 2 if workload != "infer" else 16
             cx, csem, cins, cn = R.synth_batch(cb, S, S, seed=7)
             sd = R.synth_state_dict(23, True)
             csel = [list(range(int(k))) for k in cn.view(-1)]
@@ -256,14 +258,16 @@ def main():
 
             cpu_step()
             log("cpu baseline warm rep done")
-            reps, t1 = 0, time.perf_counter()
-            while reps < 2 or (time.perf_counter() - t1 < 15.0 and reps < 20):
+            times, t1 = [], time.perf_counter()
+            while len(times) < 5 or (time.perf_counter() - t1 < 20.0 and len(times) < 20):
+                t2 = time.perf_counter()
                 cpu_step()
-                reps += 1
-            cdt = (time.perf_counter() - t1) / reps
+                times.append(time.perf_counter() - t2)
+            times.sort()
+            cdt, reps = times[len(times) // 2], len(times)
             out["cpu_baseline"] = {"value": round(cb / cdt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-                                   "kind": "port", "sample": "%d reps of the same workload at bs=%d %dx%d fp32 (oracle)" % (
-                                       reps, cb, S, S)}
+                                   "kind": "port", "sample": "median of %d reps of the same workload at bs=%d %dx%d fp32 (oracle; "
+                                   "fastest %.3f, slowest %.3f images/s)" % (reps, cb, S, S, cb / times[0], cb / times[-1])}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -117,6 +117,15 @@ int isa_conv_gemm(const isa_tensor* x, const isa_pro* pro, const void* w, int32_
 int isa_conv_gemm_ep(const isa_tensor* x, const isa_pro* pro, const void* w, int32_t kp,
                      const float* bias, const isa_tensor* y, int32_t in_mode, const isa_conv_ep* ep, void* stream);
 
+/* Whole-block forward of InvertedV1Residual in eval mode (MobileNetDenseASPP.py:68-93 under model.eval()) in ONE pass:
+ *   y = ep( pw1x1( ReLU6( bn1_scale * dw3x3(x) + bn1_shift ) ) )        ep as in isa_conv_gemm_ep (BN2 affine, residual)
+ * The depthwise output - the block's widest tensor - stays in LDS (read C + write C' instead of 3C + C' per pixel).
+ * bf16 storage; x plain (no prologue), x->c % 32 == 0 and <= 128, y->c % 16 == 0 and <= 64, h % 8 == 0, w % 32 == 0
+ * (the 256x256 ... 32x32 levels of the backbone; other shapes: ISA_EINVAL, callers use isa_dwconv3x3 +
+ * isa_conv_gemm_ep).  w_dw: packed [9][C] (isa_pack_weights kind 4), w_pw: packed [N][kp] (kind 0). */
+int isa_dwpw_eval(const isa_tensor* x, const void* w_dw, const float* bn1_scale, const float* bn1_shift,
+                  const void* w_pw, int32_t kp, const isa_conv_ep* ep, const isa_tensor* y, void* stream);
+
 /* Weight gradient of the same family, accumulated straight into the reference's state_dict layout:
  * dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)
  *   += sum_m dy[m,n] * pro(x)[m@tap, kd],  kd -> k through kmap (NULL = identity, -1 = padding).

@@ -541,10 +541,10 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x16{0};
-    const int KT = K / BK;                                         // >= 2 (K >= 128)
+    const int KT = K / BK;
     Regs R0, R1;
     fetch(R0, 0);
-    fetch(R1, 1);
+    if (KT > 1) fetch(R1, 1);
     __syncthreads();                                               // pro_tab
     stash(R0, 0, 0);
     __syncthreads();
@@ -741,7 +741,8 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     if constexpr (sizeof(T) == 2) {
         // low-resolution 1x1 layers: small GEMMs, both operands through LDS (conv_gemm_tiled_kernel)
         static const long tiled_max_m = getenv("ISA_GEMM_TILED_MAX_M") ? atol(getenv("ISA_GEMM_TILED_MAX_M")) : 65536;
-        if (in_mode == ISA_IN_1X1 && out_mode == ISA_OUT_PLAIN && p.cin == p.kp && p.kp >= 128 && p.kp % 64 == 0 && p.kp <= 2048 &&
+        static const int tiled_min_k = getenv("ISA_GEMM_TILED_MIN_K") ? atoi(getenv("ISA_GEMM_TILED_MIN_K")) : 128;
+        if (in_mode == ISA_IN_1X1 && out_mode == ISA_OUT_PLAIN && p.cin == p.kp && p.kp >= tiled_min_k && p.kp % 64 == 0 && p.kp <= 2048 &&
             p.N >= 64 && p.N % 16 == 0 && p.M <= tiled_max_m)
         {
             static const long wide_min_wgs = getenv("ISA_GEMM_TILED_WIDE_MIN") ? atol(getenv("ISA_GEMM_TILED_WIDE_MIN")) : 512;
@@ -769,7 +770,8 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     p.ntiles = (int)((p.M + 127) / 128);
     const int gy = (p.N + n_blk - 1) / n_blk;
     int gx = p.ntiles * p.G;
-    const int cap = max(1, (256 * 3) / gy);          // three resident workgroups per CU (measured: 2 -> 36.5 ms, 3 -> 36.3, 4 -> 36.9)
+    static const int wg_per_cu = getenv("ISA_GEMM_WG_PER_CU") ? atoi(getenv("ISA_GEMM_WG_PER_CU")) : 3;
+    const int cap = max(1, (256 * wg_per_cu) / gy);  // three resident workgroups per CU (measured: 2 -> 36.5 ms, 3 -> 36.3, 4 -> 36.9)
     if (gx > cap) gx = cap;
     gx = (int)group_grid(gx, p.G);
     dim3 grid(gx, gy);

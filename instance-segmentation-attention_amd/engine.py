@@ -493,6 +493,8 @@ class Engine:
         # eval mode: BatchNorm (a constant affine), activation and residual ride in the conv's output epilogue
         # (isa_conv_gemm_ep) instead of a lazy prologue in the consumer plus a materialising pass per block
         self.fuse_eval = os.environ.get("ISA_FUSE_EVAL", "1") != "0"
+        # ... and a whole InvertedV1Residual block in one launch where the shape allows (isa_dwpw_eval)
+        self.fuse_block = os.environ.get("ISA_FUSE_BLOCK", "1") != "0"
         self._pw_out: Dict[tuple, dict] = {}
         self._pw_in: Dict[tuple, dict] = {}      # conv input -> the same records: residual gradients ride along
         # eval-mode BN constants per layer: persistent buffers (a captured inference graph reads them), recomputed in
@@ -751,6 +753,29 @@ class Engine:
         self._keep_ep = (ep, res)                                  # ctypes argument lifetime: until the call returns
         L.check(self.lib.isa_conv_gemm_ep(x.d(), x.p(), self.packer.ptr(reg["fwd"]), reg["kp"], None, out.d(),
                                           L.IN_3X3 if taps == 9 else L.IN_1X1, C.byref(ep), self.st()), "isa_conv_gemm_ep")
+        return out
+
+    def block_v1_eval_fusable(self, x: Act, cout):
+        """Shapes isa_dwpw_eval is built for (see include/isa_kernels.h); ISA_FUSE_BLOCK=0 selects the two-launch path."""
+        return (self.fuse_block and self.eval_fusable() and self.dtype == torch.bfloat16 and x.pro is None and x.c % 32 == 0
+                and x.c <= 128 and cout % 16 == 0 and cout <= 64 and x.h % 8 == 0 and x.w % 32 == 0 and x.ld % 8 == 0)
+
+    def block_v1_eval(self, x: Act, pre, out: Act, res: Optional[Act] = None):
+        """Eval mode only: the whole InvertedV1Residual (dw3x3 - BN - ReLU6 - pw - BN (+x)) in ONE launch; the depthwise
+        output never leaves LDS (isa_dwpw_eval)."""
+        rd = self.reg_dw(pre + ".conv.0.weight")
+        rc = self.reg_conv(pre + ".conv.3.weight")
+        if self.packer.table is None:
+            self.packer.pack()
+        s1, h1, _, _ = self.eval_bn(pre + ".conv.1", x.c)
+        s2, h2, _, _ = self.eval_bn(pre + ".conv.4", out.c)
+        if self.profile:
+            esz = x.buf.element_size()
+            self.next_bytes = (x.n * x.h * x.w * x.c + (1 + (res is not None)) * out.n * out.h * out.w * out.c) * esz
+        ep = L.IsaConvEp(L.addr(s2), L.addr(h2), L.ACT_NONE, C.addressof(res._c) if res is not None else None)
+        self._keep_ep = (ep, res)
+        L.check(self.lib.isa_dwpw_eval(x.d(), self.packer.ptr(rd["fwd"]), L.ptr(s1), L.ptr(h1), self.packer.ptr(rc["fwd"]),
+                                       rc["kp"], C.byref(ep), out.d(), self.st()), "isa_dwpw_eval")
         return out
 
     def conv(self, x: Act, wname, out: Act, *, taps=1, bias=None, stats=False, kmap=None,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "isa_pack_weights": [VP, I32, VP, VP, VP, I32, VP],
     "isa_conv_gemm": [P_T, P_PRO, VP, I32, VP, P_T, I32, I32, VP, I32, VP],
     "isa_conv_gemm_ep": [P_T, P_PRO, VP, I32, VP, P_T, I32, VP, VP],
+    "isa_dwpw_eval": [P_T, VP, VP, VP, VP, I32, VP, P_T, VP],
     "isa_conv_wgrad": [P_T, P_PRO, P_T, VP, VP, I32, I32, VP, I32, VP, I64, VP, VP],
     "isa_colsum": [P_T, VP, VP],
     "isa_dwconv3x3": [P_T, P_PRO, VP, VP, P_T, VP, VP],

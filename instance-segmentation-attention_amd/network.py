@@ -25,6 +25,8 @@ class Network:
         E = self.E
         cin = x.c
         cout = E.params.shapes[pre + ".conv.3.weight"][0]
+        if E.block_v1_eval_fusable(x, cout):               # eval: the whole block in one launch, the dw output stays in LDS
+            return E.block_v1_eval(x, pre, out, res=x if cin == cout else None)
         y1 = E.like(x, cin)
         if E.eval_fusable():                               # eval: BN.4 and the residual ride in the 1x1 conv's epilogue
             E.dwconv(x, pre + ".conv.0.weight", y1, stats=False)

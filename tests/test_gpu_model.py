@@ -290,3 +290,41 @@ def test_graph_replayed_inference_matches_eager():
     for (se, ae), (sg, ag) in zip(eager, got):
         assert float((se - sg).abs().max() / se.abs().max()) < 1e-5
         assert float((ae != ag).float().mean()) < 1e-3
+
+
+def test_whole_block_eval_fusion_matches_the_two_launch_path():
+    """isa_dwpw_eval (InvertedV1Residual in one launch, the depthwise output resident in LDS) against the op-granular
+    eval path (isa_dwconv3x3 + isa_conv_gemm_ep) it replaces on the 256x256 ... 32x32 backbone levels: same roundings
+    by construction (the depthwise result is rounded to bf16 where the two-launch path stores it), so the two differ by
+    the summation order of the 1x1 contraction only; and against the fp32 oracle like every bf16 run."""
+    ReSeg = need_gpu()
+    x, _, _, _ = R.synth_batch(2, 256, 256, seed=1)
+    m, sd = build(ReSeg, False, torch.bfloat16, False)
+    E = m.engine
+    E.profile = True
+    outs = {}
+    for fuse in (False, True):
+        E.fuse_block = fuse
+        E.prof_events = []
+        sem_out, _ = m(False, x)
+        torch.cuda.synchronize()
+        calls = E.profile_summary()
+        outs[fuse] = sem_out.float().cpu().clone()
+        if fuse:
+            assert calls["isa_dwpw_eval"][0] >= 8 and calls.get("isa_dwconv3x3", (0,))[0] <= 10, calls
+        else:
+            assert "isa_dwpw_eval" not in calls
+    E.profile = False
+    with torch.no_grad():
+        ref = R.reseg_forward(sd, x, use_instance_seg=False)["sem_out"]
+    d = float((outs[True] - outs[False]).abs().max() / outs[False].abs().max())
+    e_f, e_u = _rel_l2(outs[True], ref), _rel_l2(outs[False], ref)
+    print("fused vs two-launch eval blocks: max-abs/max %.3e, rel-L2 %.3e; vs the fp32 oracle: fused %.3e, two-launch %.3e"
+          % (d, _rel_l2(outs[True], outs[False]), e_f, e_u))
+    # a different summation order flips last bits of bf16 roundings, which 40 layers amplify like any bf16 noise: the two
+    # paths must be equally far from the fp32 oracle and no farther from each other than either is from it
+    assert _rel_l2(outs[True], outs[False]) <= max(e_f, e_u) and d <= 0.10, d
+    assert e_f <= 1.25 * e_u + 1e-3
+    assert e_f <= 0.10
+    v, kept, _ = margin_iou(outs[True], ref, 0.05)
+    assert v >= 0.999 and kept > 0.3

@@ -552,7 +552,7 @@ def test_backbone_gradients_tight_vs_oracle_f64():
          for k, v in sd.items()}
     ref = R.reseg_forward(P, x.double(), sem, use_instance_seg=False, ctx=R.Ctx(bn_train=True, training=True))
     ce, dice = R.sem_losses(ref["sem_out"], sem)
-    assert abs(float(out["sem"][0]) - float(ce)) < 1e-4 and abs(float(out["sem"][1]) - float(dice)) < 1e-4
+    assert abs(float(out["sem"][0]) - float(ce.detach())) < 1e-4 and abs(float(out["sem"][1]) - float(dice.detach())) < 1e-4
     (ce + dice).backward()
     errs = {}
     gmax = max(float(v.grad.norm()) for v in P.values() if getattr(v, "grad", None) is not None)
