@@ -6,12 +6,13 @@
 //   a21  Decoder.forward (utils.py:59-69): sigmoid(<q_b, enc[b,:,p]>) for every pixel.
 // All three are ~1 FLOP/byte: pure HBM streaming, no MFMA (the contraction is 12-24 deep per key).
 //
-// a19 design (gfx950): one 256-thread workgroup per (batch*head, query).  K and V are streamed ONCE:
-// tiles of 256 keys x d are staged in LDS with 16-byte coalesced loads (rows are only 24-48 bytes, so
-// a lane-per-key global access would touch 64 lines per instruction), then each lane scores its key
-// from LDS and folds it into a private online softmax state (running max m, sum s, acc[d_v]).  The 256
-// states are merged with wave shuffles (64 -> 1) and a 4-entry LDS exchange.  Raw scores go to the
-// attn output on the fly and are normalised by a second, L-float pass (the reference returns attn).
+// a19 design (gfx950): the production kernel is sdp_split_kernel below - split-L streaming ("flash decoding") for the
+// reference's head width d = 12: the keys of a batch element are split over workgroups, K and V stream ONCE through an
+// LDS tile with the next tile's 16-byte loads in registers (rows are only 24-48 bytes: a lane-per-key global access
+// would touch 64 lines per instruction), lane = key with a private online-softmax state, a merge kernel combines the
+// partials.  sdp_kernel (first below) is the one-workgroup-per-query form kept ONLY for other head widths (d <= 32,
+// d != 12, heads = 1), which the reference's configuration (config.py:22-25) never produces; it is reached through the
+// same entry point and covered by the d = 16 / 32 cases of tests/test_gpu_byname.py.
 #include "common.hpp"
 
 typedef _Float16 f16_t;
@@ -174,6 +175,13 @@ __global__ __launch_bounds__(256) void sdp_split_kernel(SdpSplitParams p) {
         for (int j = 0; j < D; ++j) o[r][j] = 0.f;
     }
     f32x4 pk[NLD], pv[NLD];
+    // mask bytes of the lane's own keys travel with the tile: requested a tile ahead like K and V (read at the point of
+    // use they were a dependent global load in the scoring loop: +35 % on the whole kernel)
+    uint8_t pmask[KPL][G * NQ], cmask[KPL][G * NQ];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u)
+#pragma unroll
+        for (int r = 0; r < G * NQ; ++r) { pmask[u][r] = 0; cmask[u][r] = 0; }
     auto issue = [&](long l0) {                             // all 16-byte loads of one tile; clamped, never out of range
         const long lim = (l_end - l0) * ROWB;               // valid bytes of this tile
 #pragma unroll
@@ -183,6 +191,25 @@ __global__ __launch_bounds__(256) void sdp_split_kernel(SdpSplitParams p) {
             pk[i] = *reinterpret_cast<const f32x4*>(kg + l0 * ROWB + off);
             pv[i] = *reinterpret_cast<const f32x4*>(vg + l0 * ROWB + off);
         }
+        if (p.mask) {
+#pragma unroll
+            for (int u = 0; u < KPL; ++u) {
+                const long l = min(l0 + tid + u * 256, l_end - 1);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const int qi = min(p.q0 + i, p.lq - 1);
+                        pmask[u][g * NQ + i] = p.mask[((long)(p.mask_per_head ? g * p.B + b : b) * p.lq + qi) * p.L + l];
+                    }
+            }
+        }
+    };
+    auto take_mask = [&]() {
+#pragma unroll
+        for (int u = 0; u < KPL; ++u)
+#pragma unroll
+            for (int r = 0; r < G * NQ; ++r) cmask[u][r] = pmask[u][r];
     };
     auto commit = [&]() {
         char* kt = smem; char* vt = kt + TILE_B;
@@ -210,6 +237,7 @@ __global__ __launch_bounds__(256) void sdp_split_kernel(SdpSplitParams p) {
     __syncthreads();
     for (long l0 = l_begin; l0 < l_end; l0 += KT) {
         const bool more = l0 + KT < l_end;
+        take_mask();                                         // this tile's mask bytes (requested with its K / V)
         if (more) issue(l0 + KT);                            // in flight while this tile is scored
         const char* kt = smem; const char* vt = kt + TILE_B;
 #pragma unroll
@@ -229,17 +257,26 @@ __global__ __launch_bounds__(256) void sdp_split_kernel(SdpSplitParams p) {
                         float sc = 0.f;
 #pragma unroll
                         for (int j = 0; j < D; ++j) sc = fmaf(qr[r][j], kr[g * D + j], sc);
-                        const long mrow = ((long)(p.mask_per_head ? g * p.B + b : b) * p.lq + qi) * p.L;
-                        const bool masked = p.mask && p.mask[mrow + l] != 0;
+                        const bool masked = cmask[u][r] != 0;
                         if (masked) sc = -INFINITY;
                         if (p.attn) p.attn[((long)(g * p.B + b) * p.lq + qi) * p.L + l] = sc;
                         if (!masked) {
-                            const float mn = fmaxf(m[r], sc);
-                            const float a = __expf(m[r] - mn), e = __expf(sc - mn);      // exp(-inf) = 0 on the first key
-                            s[r] = s[r] * a + e;
+                            // online softmax with a LAZY rescale: a key that does not raise the lane's running maximum (all
+                            // but ~ln(keys per lane) of them on real scores) costs one exp and D fused multiply-adds; only a
+                            // new maximum rescales s and o.  The unconditional form (two exps, a multiply and an FMA per
+                            // element of o for every key) made the bf16 / f16 kernel instruction-bound at 3.6 TB/s.
+                            if (sc > m[r]) {
+                                const float a = __expf(m[r] - sc);                       // exp(-inf) = 0 on the first key
+                                s[r] = s[r] * a + 1.f;
 #pragma unroll
-                            for (int j = 0; j < D; ++j) o[r][j] = o[r][j] * a + e * vr[g * D + j];
-                            m[r] = mn;
+                                for (int j = 0; j < D; ++j) o[r][j] = o[r][j] * a + vr[g * D + j];
+                                m[r] = sc;
+                            } else {
+                                const float e = __expf(sc - m[r]);
+                                s[r] += e;
+#pragma unroll
+                                for (int j = 0; j < D; ++j) o[r][j] = fmaf(e, vr[g * D + j], o[r][j]);
+                            }
                         }
                     }
             }
