@@ -8,9 +8,11 @@
 // recomputing backward.
 //
 // gfx950 structure: a workgroup (256 threads) owns 8 x 32-pixel tiles, persistent over tiles.
-//   * per 32-channel block: the (8+2) x (32+2) halo is staged in LDS as fp32 (16-byte global loads, the NEXT block's or
-//     tile's loads are already in registers while the current one is computed), the stencil runs as in dwconv_tiled.hip
-//     (lane = 8 channels x 4 consecutive x, 18 LDS row vectors feed 36 packed FMAs), BN1 + ReLU6 are applied to the
+//   * per 32-channel block: the (8+2) x (32+2) halo is staged in LDS in its storage type (16-byte global loads land
+//     unconverted; the NEXT block's or tile's loads are already in registers while the current one is computed; an fp32
+//     halo cost 49 KB and left one workgroup per CU: 92 -> 85 us for the 64 -> 32 block at 256x256 x 16), the stencil runs
+//     as in dwconv_tiled.hip (lane = 8 channels x 4 consecutive x, 18 LDS row vectors feed 36 packed FMAs), BN1 + ReLU6 are
+//     applied to the
 //     accumulators and the 256 x 32 result goes to the A tile in LDS as bf16, rows padded by 16 B;
 //   * after the last channel block: A[256 px][C] x W[C'][C] on v_mfma_f32_32x32x16_bf16 (a wave owns two 32-pixel rows
 //     of the tile; both operands are conflict-free ds_read_b128 row reads, W staged once per workgroup), BN2 affine on
@@ -20,7 +22,8 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, CB = 32, PS = 36;
+constexpr int TH = 8, TW = 32, CB = 32;
+constexpr int PS = 40;     // halo pixel stride in bf16 elements: 80 B, the four x-groups of a ds_read_b128 phase tile 256 B
 constexpr int HALO = (TH + 2) * (TW + 2);
 constexpr int NIT = (HALO * 4 + 255) / 256;              // 16-byte halo slots per thread and channel block
 
@@ -53,8 +56,8 @@ template <int NT>   // output channels = 32 * NT
 __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.c, LDA = C + 8, LDW = C + 8;          // bf16 elements; +16 B keeps ds_read_b128 rows conflict-free
-    float* halo = reinterpret_cast<float*>(smem);                                   // [HALO][PS]; the epilogue's stage later
-    bf16_t* sA = reinterpret_cast<bf16_t*>(halo + HALO * PS);                       // [256][LDA]
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem);                                 // [HALO][PS]; the epilogue's stage later
+    bf16_t* sA = halo + HALO * PS;                                                  // [256][LDA]
     bf16_t* sW = sA + 256 * LDA;                                                    // [32 NT][LDW]
     float* wts = reinterpret_cast<float*>(sW + 32 * NT * LDW);                      // [9][C]
     float* bn1 = wts + 9 * C;                                                       // [2][C]
@@ -103,14 +106,11 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
         }
         asm volatile("" ::: "memory");
     };
-    auto stash = [&]() {                                   // registers -> fp32 halo tile (zero outside the image)
+    auto stash = [&]() {                                   // registers -> halo tile, unconverted (zero outside the image)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (hpix[it] < 0) continue;
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (float)regs[it][j];
-            store8<float>(halo + hpix[it] * PS + cg * 8, o);
+            *reinterpret_cast<bf16x8*>(halo + hpix[it] * PS + cg * 8) = regs[it];
         }
     };
 
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ld8(wc + (dy * 3 + k) * C, wr[k]);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) ld8(halo + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+                for (int k = 0; k < 6; ++k) load8<bf16_t>(halo + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
                     for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
             }
             // ---- epilogue: BN2 affine (lane r <-> output channel), transpose through the (idle) halo area, residual, stores
-            float* stage = halo + wave * (32 * 33);
+            float* stage = reinterpret_cast<float*>(halo) + wave * (32 * 33);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int trow = wave * 2 + i;                                   // tile row = image row ty*8 + trow
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
 template <int NT>
 int launch_dwpw(const DwPwParams& p, hipStream_t s) {
     const int C = p.c;
-    const size_t lds = (size_t)HALO * PS * 4 + (size_t)256 * (C + 8) * 2 + (size_t)32 * NT * (C + 8) * 2 + (size_t)9 * C * 4 + (size_t)2 * C * 4;
+    const size_t lds = (size_t)HALO * PS * 2 + (size_t)256 * (C + 8) * 2 + (size_t)32 * NT * (C + 8) * 2 + (size_t)9 * C * 4 + (size_t)2 * C * 4;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_eval_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
