@@ -129,7 +129,7 @@ int isa_dwpw_eval(const isa_tensor* x, const void* w_dw, const float* bn1_scale,
 /* Weight gradient of the same family, accumulated straight into the reference's state_dict layout:
  * dw[N][Ksrc][kh][kw] (or [K][Co][2][2] for ISA_OUT_SHUFFLE2)
  *   += sum_m dy[m,n] * pro(x)[m@tap, kd],  kd -> k through kmap (NULL = identity, -1 = padding).
- * dbias[N] += sum_m dy (optional, not for SHUFFLE2: use isa_colsum).
+ * dbias[N] += sum_m dy (optional; for SHUFFLE2 the sum runs over all four output quadrants).
  * Two launches, no atomics (deterministic): split-M workgroups write partial slabs into `ws`
  * (caller scratch, >= a few MB; the split factor adapts to ws_floats), a reduce kernel folds them.
  * `defer` (optional, all weight-gradient entry points): see isa_slab_arena below. */

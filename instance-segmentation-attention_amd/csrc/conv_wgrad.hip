@@ -266,7 +266,7 @@ __device__ __forceinline__ void fold_fragments(const WgReduce& q, int bx, int nb
             if (q.out_mode == ISA_OUT_SHUFFLE2) off = ((long)k * q.N + n) * 4 + tap;       // [K][Co][2][2]
             else off = ((long)n * q.ksrc + k) * q.taps + tap;                              // [N][K][kh][kw]
             atomicAdd(q.dw + off, s);
-        } else if (q.dbias && gk == 0 && tap == 0) {
+        } else if (q.dbias && gk == 0 && (tap == 0 || q.out_mode == ISA_OUT_SHUFFLE2)) {   // transposed conv: every quadrant's pixels
             const int n = n0 + (idx - q.tn * q.tk * 1024);
             if (n < q.N) atomicAdd(q.dbias + n, s);
         }
@@ -631,8 +631,7 @@ extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa
     p.in_mode = in_mode; p.out_mode = out_mode; p.ws = ws; p.ws_floats = ws_floats; p.sa = defer;
     if (out_mode == ISA_OUT_SHUFFLE2) {
         if (in_mode != ISA_IN_1X1 || dy->h != 2 * x->h || dy->w != 2 * x->w || dy->n != x->n) return ISA_EINVAL;
-        p.taps = 4; p.N = dy->c;
-        if (dbias) return ISA_EINVAL;       // bias of a transposed conv sums all quadrants: isa_colsum
+        p.taps = 4; p.N = dy->c;             // dbias: the four quadrant slabs each carry the column sums of their pixels
     } else {
         if (dy->h != x->h || dy->w != x->w || dy->n != x->n) return ISA_EINVAL;
         p.taps = in_mode == ISA_IN_3X3 ? 9 : 1; p.N = dy->c;

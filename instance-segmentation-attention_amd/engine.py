@@ -812,13 +812,12 @@ class Engine:
                 dy = self.grads.grad_of(out)
                 pk = self.packer
                 def wgrad(ws):
-                    if transposed:
-                        L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname), None,
+                    if transposed:      # the bias gradient (sum over all output pixels) rides in the four quadrant slabs
+                        L.check(self.lib.isa_conv_wgrad(x.d(), x.p(), dy.d(), self.params.gptr(wname),
+                                                        self.params.gptr(bias) if bias else None,
                                                         L.IN_1X1, L.OUT_SHUFFLE2, pk.kmap_ptr(reg["fwd"]),
                                                         self.params.shapes[wname][0], L.ptr(ws), ws.numel(),
                                                         self.defer_handle(), self.st()), "isa_conv_wgrad")
-                        if bias is not None:
-                            L.check(self.lib.isa_colsum(dy.d(), self.params.gptr(bias), self.st()), "isa_colsum")
                     else:
                         if self.profile:
                             self.next_bytes = (x.n * x.h * x.w * x.c + dy.n * dy.h * dy.w * dy.c) * x.buf.element_size()
