@@ -336,14 +336,26 @@ __global__ __launch_bounds__(64) void sdp_merge_kernel(const float* part, int ns
     float M = -INFINITY;
     for (int i = lane; i < nsplit; i += 64) M = fmaxf(M, pr[i * (2 + D)]);
     M = wave_max(M);
-    float S = 0.f;
-    for (int i = lane; i < nsplit; i += 64) { const float mi = pr[i * (2 + D)]; if (mi != -INFINITY) S += pr[i * (2 + D) + 1] * __expf(mi - M); }
+    // one pass over the lane's partials: the weight e^(m_i - M) is computed once and applied to s_i and all D values of o_i
+    // (a pass per output element recomputed it D times and made this one-wave kernel 16 us long at 256 partials)
+    float S = 0.f, acc[DMAX];
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) acc[j] = 0.f;
+    for (int i = lane; i < nsplit; i += 64) {
+        const float* q = pr + i * (2 + D);
+        const float mi = q[0];
+        if (mi == -INFINITY) continue;
+        const float w = __expf(mi - M);
+        S += q[1] * w;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) if (j < D) acc[j] = fmaf(q[2 + j], w, acc[j]);
+    }
     S = wave_sum(S);
     const int g = row / (B * lq), rem = row - g * B * lq, b = rem / lq, qi = rem - b * lq;
-    for (int j = 0; j < D; ++j) {
-        float a = 0.f;
-        for (int i = lane; i < nsplit; i += 64) { const float mi = pr[i * (2 + D)]; if (mi != -INFINITY) a += pr[i * (2 + D) + 2 + j] * __expf(mi - M); }
-        a = wave_sum(a);
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) {
+        if (j >= D) break;
+        const float a = wave_sum(acc[j]);
         // all keys masked: softmax of all -inf is NaN in the reference (utils.py:323-325); 0/0 keeps that
         if (lane == 0) st<T>::stv(out + ((long)b * lq + qi) * (G * D) + g * D + j, a / S);
     }
