@@ -165,28 +165,25 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
         __syncthreads();                                   // halo consumed (it is restaged next), A block written
         if (cb == ncb - 1) {
             // ---- 1x1 conv on the finished A tile: wave w owns tile rows 2w, 2w + 1 (32 pixels each)
-            f32x16 acc[2][NT];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = f32x16{0};
-            const bf16_t* tA = sA + (wave * 64 + r) * LDA + 8 * hh;
+            // one 32-pixel tile row at a time: NT accumulators live (two rows at once put the 64-channel variant at 264
+            // registers, one wave per SIMD)
             const bf16_t* tB = sW + r * LDW + 8 * hh;
-            for (int k = 0; k < C; k += 16) {
-                bf16x8 a[2], bb[NT];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tA + i * 32 * LDA + k);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bb[j] = *reinterpret_cast<const bf16x8*>(tB + j * 32 * LDW + k);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
-            }
-            // ---- epilogue: BN2 affine (lane r <-> output channel), transpose through the (idle) halo area, residual, stores
             float* stage = reinterpret_cast<float*>(halo) + wave * (32 * 33);
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < 2; ++i) {
+                f32x16 acc[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = f32x16{0};
+                const bf16_t* tA = sA + (wave * 64 + i * 32 + r) * LDA + 8 * hh;
+                for (int k = 0; k < C; k += 16) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(tA + k);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(tB + j * 32 * LDW + k);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[j], 0, 0, 0);
+                    }
+                }
+                // ---- epilogue: BN2 affine (lane r <-> output channel), transpose through the (idle) halo area, residual, stores
                 const int trow = wave * 2 + i;                                   // tile row = image row ty*8 + trow
                 const long pix0 = ((long)b * p.h + ty * TH + trow) * p.w + tx * TW;
 #pragma unroll
@@ -196,7 +193,7 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int rw = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        stage[rw * 33 + r] = act_apply(fmaf(acc[i][j][e], es, eh), p.act2);
+                        stage[rw * 33 + r] = act_apply(fmaf(acc[j][e], es, eh), p.act2);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
