@@ -120,18 +120,23 @@ __global__ __launch_bounds__(1024) void sp_softmax_kernel(const float* dot, cons
     __syncthreads();
     const float ht = s_ht, fw = fcw[0], fb = fcb[0];
     const float* d = dot + (long)b * L; const float* mm = m + (long)b * L;
+    // the score z = fcw * tanh(dot + ht) + fcb is evaluated ONCE per pixel and parked in the output row (-inf outside the
+    // mask); the sum and the final pass read it back from L2.  Three passes that each re-evaluated tanhf kept one CU busy
+    // for 90 us per launch (one 1024-thread workgroup owns a row: 64 pixels x 3 tanhf + 2 expf per thread).
+    float* bt = beta + (long)b * L;
     float mx = -INFINITY, cnt = 0.f;
-    for (long p = threadIdx.x; p < L; p += 1024)
-        if (mm[p] >= 0.5f) { mx = fmaxf(mx, fmaf(fw, tanhf(d[p] + ht), fb)); cnt += 1.f; }
+    for (long p = threadIdx.x; p < L; p += 1024) {
+        float z = -INFINITY;
+        if (mm[p] >= 0.5f) { z = fmaf(fw, tanhf(d[p] + ht), fb); mx = fmaxf(mx, z); cnt += 1.f; }
+        bt[p] = z;
+    }
     mx = block_max(mx, sh);
     cnt = block_sum(cnt, sh);
     float se = 0.f;
-    for (long p = threadIdx.x; p < L; p += 1024)
-        if (mm[p] >= 0.5f) se += expf(fmaf(fw, tanhf(d[p] + ht), fb) - mx);
+    for (long p = threadIdx.x; p < L; p += 1024) { const float z = bt[p]; if (z != -INFINITY) se += expf(z - mx); }
     se = block_sum(se, sh);
     const float k = cnt > 0.f ? cnt / se : 0.f;
-    for (long p = threadIdx.x; p < L; p += 1024)
-        beta[(long)b * L + p] = mm[p] >= 0.5f ? k * expf(fmaf(fw, tanhf(d[p] + ht), fb) - mx) : 0.f;
+    for (long p = threadIdx.x; p < L; p += 1024) { const float z = bt[p]; bt[p] = z != -INFINITY ? k * expf(z - mx) : 0.f; }
     if (threadIdx.x == 0 && rowstat) { rowstat[4 * b] = mx; rowstat[4 * b + 1] = se; rowstat[4 * b + 2] = cnt; rowstat[4 * b + 3] = ht; }
 }
 
@@ -273,14 +278,21 @@ __global__ __launch_bounds__(1024) void ins_softmax_kernel(const float* merge, c
     const int b = blockIdx.x, bi = b % nsrc;
     const int64_t* plane = ins + ((long)bi * nobj + idx[b]) * L;
     const float* z = merge + (long)bi * L;
+    // the int64 instance plane is read ONCE: the masked score (-inf outside the instance) is parked in the output row and the
+    // two later passes read that
+    float* al = alpha + (long)b * L;
     float mx = -INFINITY;
-    for (long p = threadIdx.x; p < L; p += 1024) if (plane[p] != 0) mx = fmaxf(mx, z[p]);
+    for (long p = threadIdx.x; p < L; p += 1024) {
+        const float v = plane[p] != 0 ? z[p] : -INFINITY;
+        mx = fmaxf(mx, v);
+        al[p] = v;
+    }
     mx = block_max(mx, sh);
     float se = 0.f;
-    for (long p = threadIdx.x; p < L; p += 1024) if (plane[p] != 0) se += expf(z[p] - mx);
+    for (long p = threadIdx.x; p < L; p += 1024) { const float v = al[p]; if (v != -INFINITY) se += expf(v - mx); }
     se = block_sum(se, sh);
     const float inv = se > 0.f ? 1.f / se : 0.f;
-    for (long p = threadIdx.x; p < L; p += 1024) alpha[(long)b * L + p] = plane[p] != 0 ? expf(z[p] - mx) * inv : 0.f;
+    for (long p = threadIdx.x; p < L; p += 1024) { const float v = al[p]; al[p] = v != -INFINITY ? expf(v - mx) * inv : 0.f; }
     if (threadIdx.x == 0 && rowstat) { rowstat[2 * b] = mx; rowstat[2 * b + 1] = se; }
 }
 

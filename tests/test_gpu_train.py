@@ -354,7 +354,9 @@ def test_deferred_weight_gradient_folds_match_immediate_folds():
     assert torch.isfinite(b).all()
     noise = float((a - a2).norm() / a.norm())
     rel = float((a - b).norm() / a.norm())
-    assert rel <= 3 * noise + 1e-5, (rel, noise)
+    # one pair of runs is a noisy estimate of the jitter (a ReLU6 threshold flip lands in one run in a few and moves the
+    # gradient by up to ~1e-2; without one two runs agree to 1e-6): the same 1e-2 floor as the stream / batching comparisons
+    assert rel <= max(3 * noise, 1e-2), (rel, noise)
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.9999, cos
 
