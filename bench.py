@@ -116,9 +116,13 @@ def main():
                 trainer.train_step_graphed(x, sem, ins, n, selected_idx=sel)
     elif workload == "train_fwd":
         model.train()
+        trainer = Trainer(model, world_size=world)
 
         def step():
-            model(True, x, sem, ins, n, selected_idx=sel)
+            if args.no_graph:
+                model(True, x, sem, ins, n, selected_idx=sel)
+            else:               # the training-mode forward alone (batch statistics, sampling, Dropout2d, losses), graph-replayed
+                trainer.train_step_graphed(x, sem, ins, n, selected_idx=sel, forward_only=True)
     else:
         model.eval()
 
@@ -134,12 +138,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if workload in ("train_step", "infer") and not args.no_graph:
+    if workload in ("train_step", "train_fwd", "infer") and not args.no_graph:
         log("graph setup: one eager step + one capture step (untimed, before the warmup steps)")
         step()
         step()
         sync_all()
-        if workload == "train_step" and trainer.static_inputs():
+        if workload in ("train_step", "train_fwd") and trainer.static_inputs():
             # the synthetic batch is resident in HBM: place it in the graph's own input buffers once, so that a step
             # is exactly the replay (a real pipeline writes each new batch into these buffers)
             gx_, gsem_, gins_ = trainer.static_inputs()[0]
@@ -176,7 +180,7 @@ def main():
             {"train_step": "train.py step fwd+bwd+update", "train_fwd": "ReSeg.forward(training) conv+attention head",
              "infer": "pred_list batched inference"}[workload], S, S, B, args.dtype),
             "global_batch": world * B, "image": [S, S], "parallelism": "dp%d" % world,
-            "launch": "eager" if (args.no_graph or workload == "train_fwd") else "hipGraph replay"},
+            "launch": "eager" if args.no_graph else "hipGraph replay"},
     }
 
     if rank == 0:
@@ -197,7 +201,7 @@ def main():
         elif workload == "infer":
             model(False, x)
         else:
-            step()
+            trainer.forward_backward(x, sem, ins, n, selected_idx=sel, backward=False)
         prof = E.profile_summary()
         E.profile = False
         if saved_streams is not None:

@@ -35,17 +35,19 @@ class Trainer:
         self._graphs = {}
 
     def forward_backward(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, capture=None,
-                         idx_dev=None, arena_key=None):
+                         idx_dev=None, arena_key=None, backward=True):
         """Forward + backward; gradients land in model.store.grad.  Returns device scalars
-        dict(sem=[ce, dice], head=[ins_cost_finite, criterion, ins_ce, ins_dice])."""
+        dict(sem=[ce, dice], head=[ins_cost_finite, criterion, ins_ce, ins_dice]).  backward=False: the training-mode
+        forward alone (batch statistics, sampling, Dropout2d, losses; no tape) - the forward-only benchmark line."""
         m = self.model
         E, net, st = m.engine, m.net, m.store
         dev = st.device
         x = x.to(device=dev) if x.dtype == torch.uint8 else x.to(device=dev, dtype=torch.float32)
         sem = sem.to(dev).contiguous()
         ins = ins.to(dev).contiguous()
-        st.grad[:st.n_train].zero_()
-        E.begin(bn_train=m.training, record=True,
+        if backward:
+            st.grad[:st.n_train].zero_()
+        E.begin(bn_train=m.training, record=backward,
                 key=arena_key or ("train", tuple(x.shape), x.dtype, tuple(ins.shape), ins.dtype,
                                   injected_s_t is not None))
         if getattr(m, "_weights_dirty", True) and E.packer.entries:
@@ -71,7 +73,8 @@ class Trainer:
                                  idx_dev=idx_dev)
             m.last_record = rec
             head_scal = rec["scal"]
-        E.backward()
+        if backward:
+            E.backward()
         self.last = dict(sem=sem_scal, head=head_scal)
         return self.last
 
@@ -106,13 +109,14 @@ class Trainer:
         return out
 
     # ------------------------------------------------------------------ hipGraph-captured step
-    def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None):
+    def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, forward_only=False):
         """Same step, replayed from a hipGraph: the ~2700 launches of forward+backward (+ the fused update when
         world_size == 1) are recorded once per (shapes, iteration count) and replayed, so the GPU never waits
         for the Python launch loop.  Inputs are copied into static device buffers; the per-step host decisions
         (instance order) travel through a small staged index tensor; dropout masks come from torch's graph-safe
         generator.  The first call of a configuration runs eagerly (allocations settle), the second captures.
-        With world_size > 1 the RCCL all-reduce and the update stay outside the graph."""
+        With world_size > 1 the RCCL all-reduce and the update stay outside the graph.
+        forward_only: capture and replay the training-mode forward alone (no gradients, no update)."""
         m = self.model
         st = m.store
         dev = st.device
@@ -126,16 +130,21 @@ class Trainer:
                 random.shuffle(order)
                 selected_idx.append(order)
         key = (tuple(x.shape), tuple(sem.shape), tuple(ins.shape), max_iter, bool(m.training), self.world,
-               m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8, ins.dtype == torch.uint8)
+               m.engine.dtype, injected_s_t is not None, x.dtype == torch.uint8, ins.dtype == torch.uint8, bool(forward_only))
         slot = self._graphs.get(key)
         akey = ("train_graph",) + key            # the captured configuration owns its arena (frozen after capture)
         self.sync_lr()
+        def eager(arena_key=None):
+            if forward_only:
+                return self.forward_backward(x, sem, ins, n_objects, selected_idx, injected_s_t, arena_key=arena_key,
+                                             backward=False)
+            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t,
+                                   arena_key=arena_key)
         if slot is None:                         # first sight: eager step, remember the configuration
             self._graphs[key] = dict(state="warm")
-            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t,
-                                   arena_key=akey)
+            return eager(akey)
         if slot["state"] == "eager":
-            return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
+            return eager()
         if slot["state"] == "warm":
             slot["x"] = torch.empty(tuple(x.shape), dtype=torch.uint8 if x.dtype == torch.uint8 else torch.float32,
                                     device=dev)
@@ -151,8 +160,8 @@ class Trainer:
                 # thread_local: the RCCL watchdog thread may query events while this thread captures
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = self.forward_backward(slot["x"], slot["sem"], slot["ins"], n_ins, idx_dev=slot["idx"],
-                                                injected_s_t=slot["inj"], arena_key=akey)
-                    if self.world == 1:
+                                                injected_s_t=slot["inj"], arena_key=akey, backward=not forward_only)
+                    if self.world == 1 and not forward_only:
                         self.apply_update()
                 m.engine.freeze_arena()
             except Exception as e:                 # capture refused (driver / collective state): stay eager, loudly
@@ -162,7 +171,7 @@ class Trainer:
                 torch.cuda.synchronize()
                 st.int_buffers.update(before)
                 slot["state"] = "eager"
-                return self.train_step(x, sem, ins, n_objects, selected_idx=selected_idx, injected_s_t=injected_s_t)
+                return eager()
             # capture only records: undo its host-side counters, replay() below performs the step
             slot["bumps"] = {k: v - before[k] for k, v in st.int_buffers.items() if v != before[k]}
             st.int_buffers.update(before)
@@ -172,9 +181,10 @@ class Trainer:
         slot["graph"].replay()
         for k, v in slot["bumps"].items():
             st.int_buffers[k] += v
-        if self.world > 1:
-            self.apply_update()
-        m.mark_weights_dirty()
+        if not forward_only:
+            if self.world > 1:
+                self.apply_update()
+            m.mark_weights_dirty()
         self.last = slot["out"]
         return self.last
 

@@ -613,3 +613,35 @@ def test_bf16_gradients_256_vs_reference_f64():
 BF16_GRAD_COS = 0.92
 BF16_GRAD_MEDIAN = {"backbone": 0.70, "stems+heads": 0.18, "decoder": 0.52}
 BF16_GRAD_P90 = {"backbone": 0.92, "stems+heads": 0.385, "decoder": 1.02}
+
+
+def test_forward_only_graph_matches_the_eager_forward():
+    """Trainer.train_step_graphed(forward_only=True) - the forward-only benchmark line: the training-mode forward captured
+    without tape, gradients or update.  Loss scalars equal the eager forward's; parameters and the gradient buffer stay
+    untouched; BatchNorm running statistics and num_batches_tracked advance exactly as in an eager training forward."""
+    m, tr, (x, sem, ins, n), order, inj = _graph_fixture()
+    snap = dict(flat=m.store.flat.clone(), ib=dict(m.store.int_buffers))
+    m.store.grad.fill_(3.0)
+
+    def restore():
+        m.store.flat.copy_(snap["flat"]); m.store.int_buffers.update(snap["ib"]); m.head.baseline = None
+
+    restore()
+    ref = tr.forward_backward(x, sem, ins, n, selected_idx=order, injected_s_t=inj, backward=False)
+    torch.cuda.synchronize()
+    ref_s = [float(v) for v in ref["head"][1:]] + [float(v) for v in ref["sem"]]
+    flat_ref, ib_ref = m.store.flat.clone(), dict(m.store.int_buffers)
+    n_train = m.store.n_train
+    assert torch.equal(flat_ref[:n_train], snap["flat"][:n_train])                 # no update
+    assert float((flat_ref[m.store.buffer_start:] - snap["flat"][m.store.buffer_start:]).abs().max()) > 0   # running statistics moved
+    for i in range(3):                                   # eager first sight, capture, replay
+        restore()
+        out = tr.train_step_graphed(x, sem, ins, n, selected_idx=order, injected_s_t=inj, forward_only=True)
+        torch.cuda.synchronize()
+        got = [float(v) for v in out["head"][1:]] + [float(v) for v in out["sem"]]
+        for u, v in zip(got, ref_s):
+            assert abs(u - v) <= 1e-4 * max(1.0, abs(v)), (i, got, ref_s)
+        assert float((m.store.flat - flat_ref).abs().max()) <= 1e-5 * float(flat_ref.abs().max()), i
+        assert dict(m.store.int_buffers) == ib_ref, i
+    assert any(s.get("state") == "ready" for s in tr._graphs.values())
+    assert float((m.store.grad - 3.0).abs().max()) == 0.0                          # the gradient buffer was never touched
