@@ -366,50 +366,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // row-wise stores: lane -> (row = lane>>1, 16 channels at (lane&1)*16)
-            const int row = lane >> 1, cseg = (lane & 1) * 16;
-            const long mr = mbase + row;
-            const int nseg = n0 + t * 32 + cseg;
-            if (mr < p.M && nseg < p.N) {
-                T* dst;
-                if constexpr (OUT_MODE == ISA_OUT_SHUFFLE2) {
-                    const unsigned mu = (unsigned)mr, q = mu / (unsigned)p.mw;
-                    const int ox = (int)(mu - q * (unsigned)p.mw);
-                    const int ob = (int)(q / (unsigned)p.mh); const int oy = (int)(q - (unsigned)ob * (unsigned)p.mh);
-                    const int quad = nseg / p.cout, co = nseg - quad * p.cout;
-                    dst = reinterpret_cast<T*>(p.y) +
-                          (((long)ob * p.oh + 2 * oy + (quad >> 1)) * p.ow + 2 * ox + (quad & 1)) * p.ldy + co;
-                } else {
-                    dst = reinterpret_cast<T*>(p.y) + mr * p.ldy + nseg;
-                }
-                float v[16];
+            // row-wise stores, two passes of 16 rows: lane -> (row = lane >> 2, 8 channels at (lane & 3) * 8), so the four lanes
+            // of a row write its 32 channels as ONE contiguous piece per store instruction.  (The earlier mapping - two lanes
+            // per row, two 16-byte stores each - put non-adjacent 16-byte pieces of every row into each instruction: a pure
+            // memory kernel with that store pattern runs 14-42 % below the contiguous one, profiles/r03_access_pattern_probe.txt.)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = stage[row * 33 + cseg + j];
-                if (EP && p.res) {                                 // residual branch (16 channels of this row)
-                    const T* rs = reinterpret_cast<const T*>(p.res) + mr * p.ldres + nseg;
+            for (int half = 0; half < 2; ++half) {
+                const int row = (lane >> 2) + 16 * half, cseg = (lane & 3) * 8;
+                const long mr = mbase + row;
+                const int nseg = n0 + t * 32 + cseg;
+                if (mr < p.M && nseg < p.N) {
+                    T* dst;
+                    if constexpr (OUT_MODE == ISA_OUT_SHUFFLE2) {
+                        const unsigned mu = (unsigned)mr, q = mu / (unsigned)p.mw;
+                        const int ox = (int)(mu - q * (unsigned)p.mw);
+                        const int ob = (int)(q / (unsigned)p.mh); const int oy = (int)(q - (unsigned)ob * (unsigned)p.mh);
+                        const int quad = nseg / p.cout, co = nseg - quad * p.cout;
+                        dst = reinterpret_cast<T*>(p.y) +
+                              (((long)ob * p.oh + 2 * oy + (quad >> 1)) * p.ow + 2 * ox + (quad & 1)) * p.ldy + co;
+                    } else {
+                        dst = reinterpret_cast<T*>(p.y) + mr * p.ldy + nseg;
+                    }
+                    float v[8];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (nseg + j < p.N) v[j] += st<T>::ld(rs + j);
-                }
-                const bool full = (nseg + 16 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-                if (full) {
-                    float lo[8], hi[8];
-                    if (p.accumulate) {
-                        load8<T>(dst, lo); load8<T>(dst + 8, hi);
+                    for (int j = 0; j < 8; ++j) v[j] = stage[row * 33 + cseg + j];
+                    if (EP && p.res) {                             // residual branch (8 channels of this row)
+                        const T* rs = reinterpret_cast<const T*>(p.res) + mr * p.ldres + nseg;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { lo[j] += v[j]; hi[j] += v[8 + j]; }
+                        for (int j = 0; j < 8; ++j)
+                            if (nseg + j < p.N) v[j] += st<T>::ld(rs + j);
+                    }
+                    const bool full = (nseg + 8 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+                    if (full) {
+                        if (p.accumulate) {
+                            float old[8];
+                            load8<T>(dst, old);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += old[j];
+                        }
+                        store8<T>(dst, v);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { lo[j] = v[j]; hi[j] = v[8 + j]; }
-                    }
-                    store8<T>(dst, lo); store8<T>(dst + 8, hi);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        if (nseg + j < p.N) {
-                            float o = v[j];
-                            if (p.accumulate) o += st<T>::ld(dst + j);
-                            st<T>::stv(dst + j, o);
+                        for (int j = 0; j < 8; ++j) {
+                            if (nseg + j < p.N) {
+                                float o = v[j];
+                                if (p.accumulate) o += st<T>::ld(dst + j);
+                                st<T>::stv(dst + j, o);
+                            }
                         }
                     }
                 }
@@ -603,39 +606,39 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int row = lane >> 1, cseg = (lane & 1) * 16;
-            const long mr = mbase + row;
-            const int nseg = nb + cseg;
-            if (mr < p.M && nseg < p.N) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + mr * p.ldy + nseg;
-                float v[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = stage[row * 33 + cseg + q];
-                if (EP && p.res) {
-                    const bf16_t* rs = reinterpret_cast<const bf16_t*>(p.res) + mr * p.ldres + nseg;
+            for (int half = 0; half < 2; ++half) {                 // four lanes per row: contiguous 32-channel pieces (see conv_gemm_kernel)
+                const int row = (lane >> 2) + 16 * half, cseg = (lane & 3) * 8;
+                const long mr = mbase + row;
+                const int nseg = nb + cseg;
+                if (mr < p.M && nseg < p.N) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + mr * p.ldy + nseg;
+                    float v[8];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (nseg + q < p.N) v[q] += st<bf16_t>::ld(rs + q);
-                }
-                const bool full = (nseg + 16 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-                if (full) {
-                    float lo[8], hi[8];
-                    if (p.accumulate) {
-                        load8<bf16_t>(dst, lo); load8<bf16_t>(dst + 8, hi);
+                    for (int q = 0; q < 8; ++q) v[q] = stage[row * 33 + cseg + q];
+                    if (EP && p.res) {
+                        const bf16_t* rs = reinterpret_cast<const bf16_t*>(p.res) + mr * p.ldres + nseg;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { lo[q] += v[q]; hi[q] += v[8 + q]; }
+                        for (int q = 0; q < 8; ++q)
+                            if (nseg + q < p.N) v[q] += st<bf16_t>::ld(rs + q);
+                    }
+                    const bool full = (nseg + 8 <= p.N) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+                    if (full) {
+                        if (p.accumulate) {
+                            float old[8];
+                            load8<bf16_t>(dst, old);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += old[q];
+                        }
+                        store8<bf16_t>(dst, v);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { lo[q] = v[q]; hi[q] = v[8 + q]; }
-                    }
-                    store8<bf16_t>(dst, lo); store8<bf16_t>(dst + 8, hi);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        if (nseg + q < p.N) {
-                            float o = v[q];
-                            if (p.accumulate) o += st<bf16_t>::ld(dst + q);
-                            st<bf16_t>::stv(dst + q, o);
+                        for (int q = 0; q < 8; ++q) {
+                            if (nseg + q < p.N) {
+                                float o = v[q];
+                                if (p.accumulate) o += st<bf16_t>::ld(dst + q);
+                                st<bf16_t>::stv(dst + q, o);
+                            }
                         }
                     }
                 }

@@ -197,24 +197,22 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    const int px = lane >> 1, cseg = (lane & 1) * 16;
-                    const int nseg = j * 32 + cseg;
-                    if (nseg < p.N) {
-                        float v[16];
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) v[q] = stage[px * 33 + cseg + q];
-                        if (p.res) {
-                            const bf16_t* rs = p.res + (pix0 + px) * p.ldres + nseg;
-                            float r0[8], r1[8];
-                            load8<bf16_t>(rs, r0); load8<bf16_t>(rs + 8, r1);
+                    for (int half = 0; half < 2; ++half) {         // four lanes per pixel row: contiguous 32-channel pieces
+                        const int px = (lane >> 2) + 16 * half, cseg = (lane & 3) * 8;
+                        const int nseg = j * 32 + cseg;
+                        if (nseg < p.N) {
+                            float v[8];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) { v[q] += r0[q]; v[8 + q] += r1[q]; }
+                            for (int q = 0; q < 8; ++q) v[q] = stage[px * 33 + cseg + q];
+                            if (p.res) {
+                                float r0[8];
+                                load8<bf16_t>(p.res + (pix0 + px) * p.ldres + nseg, r0);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] += r0[q];
+                            }
+                            store8<bf16_t>(p.y + (pix0 + px) * p.ldy + nseg, v);
                         }
-                        bf16_t* dst = p.y + (pix0 + px) * p.ldy + nseg;
-                        float lo[8], hi[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) { lo[q] = v[q]; hi[q] = v[8 + q]; }
-                        store8<bf16_t>(dst, lo); store8<bf16_t>(dst + 8, hi);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -255,7 +253,7 @@ extern "C" int isa_dwpw_eval(const isa_tensor* x, const void* w_dw, const float*
     if (x->dtype != ISA_BF16 || y->dtype != ISA_BF16) return ISA_EDTYPE;
     if (x->n != y->n || x->h != y->h || x->w != y->w) return ISA_EINVAL;
     // shapes this kernel is built for (the 256x256 ... 32x32 levels of the backbone): whole tiles, whole channel blocks
-    if (x->c % CB || x->c > 128 || y->c % 16 || y->c > 64 || x->h % TH || x->w % TW || kp < x->c || kp % 32) return ISA_EINVAL;
+    if (x->c % CB || x->c > 128 || y->c % 8 || y->c > 64 || x->h % TH || x->w % TW || kp < x->c || kp % 32) return ISA_EINVAL;
     DwPwParams p{};
     p.x = (const bf16_t*)x->data; p.n = x->n; p.h = x->h; p.w = x->w; p.c = x->c; p.ldx = x->ld;
     p.wdw = (const bf16_t*)w_dw; p.wld = ((x->c + 7) / 8) * 8;
