@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     const int b_bytes = (N_BLK * p.ldb * (int)sizeof(T) + 15) & ~15;
     float* pro_tab = reinterpret_cast<float*>(smem + b_bytes);          // [2][kp]
     const int pro_bytes = HAS_PRO ? 2 * p.kp * 4 : 0;
-    float* stage = reinterpret_cast<float*>(smem + b_bytes + pro_bytes) + wave * (32 * 33);
+    float* stage = reinterpret_cast<float*>(smem + b_bytes + pro_bytes) + wave * (32 * (NT == 2 ? 65 : 33));
 
     if constexpr (HAS_PRO) {
         for (int k = tid; k < p.kp; k += 256) {
@@ -343,38 +343,49 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
         }
 
         // ---------------- epilogue: lane r <-> output channel n0+t*32+r -------------------------
+        // NTS column tiles are transposed through the per-wave LDS stage together and leave as whole rows: with two tiles
+        // (64 output channels) a row is one 128-byte line in bf16 - written half a line at a time (one tile after the
+        // other) the same kernel lost a quarter of its bandwidth (profiles/r03_access_pattern_probe.txt: read 32 + write 64
+        // 3.4 vs 5.8 TB/s).  Four-tile launches (low-resolution levels, column blocks of 128) keep one tile per pass.
+        constexpr int NTS = NT == 2 ? 2 : 1;                   // tiles staged together
+        constexpr int SR = 32 * NTS + 1;                       // stage row stride (floats)
+        constexpr int LPR = 4 * NTS;                           // lanes per row in the store phase (8 channels each)
         const long mbase = (long)tile * 128 + wave * 32;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t * 32 + r;
-            // bias is per output channel; in pixel-shuffle mode GEMM column n = quadrant*cout + co
-            const float bv = (p.bias && n < p.N) ? p.bias[OUT_MODE == ISA_OUT_SHUFFLE2 ? n % p.cout : n] : 0.f;
-            constexpr bool has_ep = EP;
-            const float es = (has_ep && n < p.N) ? p.ep_scale[n] : 1.f, eh = (has_ep && n < p.N) ? p.ep_shift[n] : 0.f;
-            float s = 0.f, s2 = 0.f;
+        for (int t0 = 0; t0 < NT; t0 += NTS) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                float v = acc[t][i] + bv;
-                if (has_ep) v = act_apply(fmaf(v, es, eh), p.ep_act);
-                if (mbase + row < p.M) { s += v; s2 += v * v; }
-                stage[row * 33 + r] = v;
-            }
-            if (p.stats) {
-                s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                st_sum[t] += s; st_sq[t] += s2;
+            for (int tt = 0; tt < NTS; ++tt) {
+                const int t = t0 + tt;
+                const int n = n0 + t * 32 + r;
+                // bias is per output channel; in pixel-shuffle mode GEMM column n = quadrant*cout + co
+                const float bv = (p.bias && n < p.N) ? p.bias[OUT_MODE == ISA_OUT_SHUFFLE2 ? n % p.cout : n] : 0.f;
+                constexpr bool has_ep = EP;
+                const float es = (has_ep && n < p.N) ? p.ep_scale[n] : 1.f, eh = (has_ep && n < p.N) ? p.ep_shift[n] : 0.f;
+                float s = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    float v = acc[t][i] + bv;
+                    if (has_ep) v = act_apply(fmaf(v, es, eh), p.ep_act);
+                    if (mbase + row < p.M) { s += v; s2 += v * v; }
+                    stage[row * SR + tt * 32 + r] = v;
+                }
+                if (p.stats) {
+                    s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                    st_sum[t] += s; st_sq[t] += s2;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // row-wise stores, two passes of 16 rows: lane -> (row = lane >> 2, 8 channels at (lane & 3) * 8), so the four lanes
-            // of a row write its 32 channels as ONE contiguous piece per store instruction.  (The earlier mapping - two lanes
-            // per row, two 16-byte stores each - put non-adjacent 16-byte pieces of every row into each instruction: a pure
-            // memory kernel with that store pattern runs 14-42 % below the contiguous one, profiles/r03_access_pattern_probe.txt.)
+            // row-wise stores: lane -> (row = lane / LPR, 8 channels at (lane % LPR) * 8): the LPR lanes of a row write its
+            // 32 * NTS channels as ONE contiguous piece per store instruction.  (The first mapping - two lanes per row, two
+            // 16-byte stores each - put non-adjacent 16-byte pieces of every row into each instruction: a pure memory kernel
+            // with that store pattern runs 14-42 % below the contiguous one.)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int row = (lane >> 2) + 16 * half, cseg = (lane & 3) * 8;
+            for (int pass = 0; pass < LPR / 2; ++pass) {
+                const int row = lane / LPR + (64 / LPR) * pass, cseg = (lane % LPR) * 8;
                 const long mr = mbase + row;
-                const int nseg = n0 + t * 32 + cseg;
+                const int nseg = n0 + t0 * 32 + cseg;
                 if (mr < p.M && nseg < p.N) {
                     T* dst;
                     if constexpr (OUT_MODE == ISA_OUT_SHUFFLE2) {
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
                     }
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = stage[row * 33 + cseg + j];
+                    for (int j = 0; j < 8; ++j) v[j] = stage[row * SR + cseg + j];
                     if (EP && p.res) {                             // residual branch (8 channels of this row)
                         const T* rs = reinterpret_cast<const T*>(p.res) + mr * p.ldres + nseg;
 #pragma unroll
@@ -769,7 +780,7 @@ int launch0(GemmParams& p, bool has_pro, int in_mode, int out_mode, hipStream_t 
     p.groups_per_chunk = gpc;
     p.ldb = gpc * 32 + 16 / (int)sizeof(T);
     const size_t b_bytes = ((size_t)n_blk * p.ldb * sizeof(T) + 15) & ~(size_t)15;
-    const size_t lds = b_bytes + (has_pro ? 2 * (size_t)p.kp * 4 : 0) + 4 * 32 * 33 * 4;
+    const size_t lds = b_bytes + (has_pro ? 2 * (size_t)p.kp * 4 : 0) + 4 * 32 * (nt == 2 ? 65 : 33) * 4;
     p.ntiles = (int)((p.M + 127) / 128);
     const int gy = (p.N + n_blk - 1) / n_blk;
     int gx = p.ntiles * p.G;
