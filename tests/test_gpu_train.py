@@ -645,3 +645,47 @@ def test_forward_only_graph_matches_the_eager_forward():
         assert dict(m.store.int_buffers) == ib_ref, i
     assert any(s.get("state") == "ready" for s in tr._graphs.values())
     assert float((m.store.grad - 3.0).abs().max()) == 0.0                          # the gradient buffer was never touched
+
+
+def test_four_iterations_with_batch_statistics_all_paths_agree():
+    """A module in train() mode called with training=False and ground truth runs as many decoder iterations as the smallest
+    image has objects (attenet2.py:377-380) with batch-statistic BatchNorm: here four.  The same layer then updates its
+    running statistics four times.  Three ways to run it must agree in every level's activations, running statistics,
+    num_batches_tracked and loss scalars: one pass per iteration on one stream; on two streams (iterations >= 1 queue their
+    updates, isa_bn_running_update applies them in order - two updates of one layer never share a launch); and
+    the batched pass with FOUR statistic groups."""
+    ReSeg, Trainer = need_gpu()
+    x, sem, ins, n = R.synth_batch(2, 64, 64, seed=2)
+    assert min(int(v) for v in n.view(-1)) == 4
+    m = ReSeg(2, True, dtype=torch.float32)
+    m.load_state_dict(R.synth_state_dict(23, True))
+    m.train()
+    m.head.drop_rate = 0.0
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    sel = [list(range(int(k))) for k in n.view(-1)]
+
+    def run(batched, streams):
+        m.load_state_dict(state0)
+        m.head.baseline = None
+        m.head.batch_iters, m.head.streams = batched, streams
+        cap = {}
+        out = m(False, x, sem, ins, n, selected_idx=sel, capture=cap)
+        torch.cuda.synchronize()
+        acts = {k: v.nchw().clone() for k, v in cap.items() if k.startswith("it")}
+        sd = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        return acts, sd, [float(v) for v in out[3:]]
+
+    a1, s1, h1 = run(False, 1)
+    assert len(a1) == 4 * 5 * 2
+    assert int(s1["decoder.bone.upAtten4.UpAtten.conv1.1.num_batches_tracked"]) == 4
+    for name, (aN, sN, hN) in (("two streams", run(False, 2)), ("batched", run(True, 1))):
+        assert set(aN) == set(a1), name
+        for k in a1:
+            assert float((a1[k] - aN[k]).abs().max()) <= 1e-4 * max(1.0, float(a1[k].abs().max())), (name, k)
+        for k in s1:
+            if "num_batches" in k:
+                assert int(s1[k]) == int(sN[k]), (name, k)
+            else:
+                assert float((s1[k] - sN[k]).abs().max()) <= 1e-5 * max(1.0, float(s1[k].abs().max())), (name, k)
+        for u, v in zip(h1, hN):
+            assert abs(u - v) <= 1e-5 * max(1.0, abs(u)), (name, h1, hN)
