@@ -110,7 +110,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ hipGraph-captured step
     def train_step_graphed(self, x, sem, ins, n_objects, selected_idx=None, injected_s_t=None, forward_only=False):
-        """Same step, replayed from a hipGraph: the ~2700 launches of forward+backward (+ the fused update when
+        """Same step, replayed from a hipGraph: the ~880 launches of forward+backward (+ the fused update when
         world_size == 1) are recorded once per (shapes, iteration count) and replayed, so the GPU never waits
         for the Python launch loop.  Inputs are copied into static device buffers; the per-step host decisions
         (instance order) travel through a small staged index tensor; dropout masks come from torch's graph-safe
