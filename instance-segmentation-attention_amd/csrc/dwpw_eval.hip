@@ -23,7 +23,9 @@
 namespace {
 
 constexpr int TH = 8, TW = 32, CB = 32;
-constexpr int PS = 40;     // halo pixel stride in bf16 elements: 80 B, the four x-groups of a ds_read_b128 phase tile 256 B
+// halo pixel stride: bf16 tiles 40 elements (80 B: the four x-groups of a ds_read_b128 phase tile 256 B), fp32 tiles 36 floats
+template <typename HT> struct halo_stride { static constexpr int v = 36; };
+template <> struct halo_stride<bf16_t> { static constexpr int v = 40; };
 constexpr int HALO = (TH + 2) * (TW + 2);
 constexpr int NIT = (HALO * 4 + 255) / 256;              // 16-byte halo slots per thread and channel block
 
@@ -52,12 +54,15 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
 }
 
-template <int NT>   // output channels = 32 * NT
+// HT: type of the halo tile in LDS.  float for C = 32 (49 KB: two workgroups per CU still fit and the stencil reads need no
+// bf16 -> fp32 conversions - 4.5 per output element, as many instructions as its packed FMAs), bf16 for wider inputs.
+template <int NT, typename HT>   // output channels = 32 * NT
 __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
+    constexpr int PS = halo_stride<HT>::v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = p.c, LDA = C + 8, LDW = C + 8;          // bf16 elements; +16 B keeps ds_read_b128 rows conflict-free
-    bf16_t* halo = reinterpret_cast<bf16_t*>(smem);                                 // [HALO][PS]; the epilogue's stage later
-    bf16_t* sA = halo + HALO * PS;                                                  // [256][LDA]
+    HT* halo = reinterpret_cast<HT*>(smem);                                         // [HALO][PS]; the epilogue's stage later
+    bf16_t* sA = reinterpret_cast<bf16_t*>(halo + HALO * PS);                       // [256][LDA]
     bf16_t* sW = sA + 256 * LDA;                                                    // [32 NT][LDW]
     float* wts = reinterpret_cast<float*>(sW + 32 * NT * LDW);                      // [9][C]
     float* bn1 = wts + 9 * C;                                                       // [2][C]
@@ -110,7 +115,13 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (hpix[it] < 0) continue;
-            *reinterpret_cast<bf16x8*>(halo + hpix[it] * PS + cg * 8) = regs[it];
+            if constexpr (sizeof(HT) == 2) *reinterpret_cast<bf16x8*>(halo + hpix[it] * PS + cg * 8) = regs[it];
+            else {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (float)regs[it][j];
+                store8<float>(reinterpret_cast<float*>(halo) + hpix[it] * PS + cg * 8, o);
+            }
         }
     };
 
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ld8(wc + (dy * 3 + k) * C, wr[k]);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) load8<bf16_t>(halo + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
+                for (int k = 0; k < 6; ++k) load8<HT>(halo + ((row + dy) * (TW + 2) + x0 + k) * PS + cg * 8, in[k]);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -226,13 +237,13 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(DwPwParams p) {
     }
 }
 
-template <int NT>
+template <int NT, typename HT>
 int launch_dwpw(const DwPwParams& p, hipStream_t s) {
     const int C = p.c;
-    const size_t lds = (size_t)HALO * PS * 2 + (size_t)256 * (C + 8) * 2 + (size_t)32 * NT * (C + 8) * 2 + (size_t)9 * C * 4 + (size_t)2 * C * 4;
+    const size_t lds = (size_t)HALO * halo_stride<HT>::v * sizeof(HT) + (size_t)256 * (C + 8) * 2 + (size_t)32 * NT * (C + 8) * 2 + (size_t)9 * C * 4 + (size_t)2 * C * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_eval_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_eval_kernel<NT, HT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 150 * 1024) != hipSuccess) return ISA_ELAUNCH;
         configured = true;
     }
@@ -240,7 +251,7 @@ int launch_dwpw(const DwPwParams& p, hipStream_t s) {
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
     long gx = 256L * (per_cu > 3 ? 3 : per_cu);
     if (gx > p.ntiles) gx = p.ntiles;
-    hipLaunchKernelGGL(dwpw_eval_kernel<NT>, dim3((unsigned)gx), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((dwpw_eval_kernel<NT, HT>), dim3((unsigned)gx), dim3(256), lds, s, p);
     return launch_status();
 }
 
@@ -268,6 +279,6 @@ extern "C" int isa_dwpw_eval(const isa_tensor* x, const void* w_dw, const float*
     p.y = (bf16_t*)y->data; p.N = y->c; p.ldy = y->ld;
     p.tiles_x = x->w / TW; p.tiles_y = x->h / TH;
     p.ntiles = (long)x->n * p.tiles_x * p.tiles_y;
-    if (y->c <= 32) return launch_dwpw<1>(p, as_stream(stream));
-    return launch_dwpw<2>(p, as_stream(stream));
+    if (x->c == 32) return y->c <= 32 ? launch_dwpw<1, float>(p, as_stream(stream)) : launch_dwpw<2, float>(p, as_stream(stream));
+    return y->c <= 32 ? launch_dwpw<1, bf16_t>(p, as_stream(stream)) : launch_dwpw<2, bf16_t>(p, as_stream(stream));
 }
