@@ -279,6 +279,7 @@ extern "C" int isa_dwpw_eval(const isa_tensor* x, const void* w_dw, const float*
     p.y = (bf16_t*)y->data; p.N = y->c; p.ldy = y->ld;
     p.tiles_x = x->w / TW; p.tiles_y = x->h / TH;
     p.ntiles = (long)x->n * p.tiles_x * p.tiles_y;
-    if (x->c == 32) return y->c <= 32 ? launch_dwpw<1, float>(p, as_stream(stream)) : launch_dwpw<2, float>(p, as_stream(stream));
+    // fp32 halo where it costs no occupancy: C = 32 (two workgroups per CU either way) and C = 128 (one either way)
+    if (x->c == 32 || x->c == 128) return y->c <= 32 ? launch_dwpw<1, float>(p, as_stream(stream)) : launch_dwpw<2, float>(p, as_stream(stream));
     return y->c <= 32 ? launch_dwpw<1, bf16_t>(p, as_stream(stream)) : launch_dwpw<2, bf16_t>(p, as_stream(stream));
 }
