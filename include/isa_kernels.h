@@ -57,11 +57,37 @@ typedef struct isa_tensor {
                        statistics or constants ignore the field. */
 } isa_tensor;
 
+/* A train-mode BatchNorm finalize that has NOT run yet, handed to the consumer of the lazy tensor (isa_pro.fin): the
+ * consuming kernel derives scale/shift from the producer's statistics itself - every workgroup for its own statistic
+ * group, into LDS - and ONE workgroup of the launch does what isa_bn_finalize does to memory: scale/shift/mean/invstd
+ * [G][c] (read later by the backward entry points) and, when running_mean/var are given, the G ordered running-statistic
+ * updates.  The arithmetic is isa_bn_finalize's (the same device function).  It removes a ~5 us launch from the dependency
+ * chain of every BatchNorm (nn.BatchNorm2d forward in train mode, torch/nn/modules/batchnorm.py; the reference's
+ * MobileNetDenseASPP.py:68-123 blocks have three each).  Entry points that take an isa_pro but have no in-kernel form
+ * (isa_chan_mean, the non-tiled depthwise fallback, the weight-gradient and fused backward entry points, the eval-epilogue
+ * GEMM) run isa_bn_finalize on the same stream first, so
+ * a non-NULL fin is always honoured.  c <= ISA_FIN_MAX_C in-kernel, wider layers take the launch. */
+#define ISA_FIN_MAX_C 1024
+typedef struct isa_bn_fin {
+    const float* stats;        /* [G][ISA_STAT_REPLICAS][2c] sums of the batch, complete on this stream */
+    const float* gamma;        /* [c] or NULL (1) */
+    const float* beta;         /* [c] or NULL (0) */
+    float* running_mean;       /* [c] or NULL: no running-statistics update by this consumer */
+    float* running_var;
+    float* scale;              /* [G][c] outputs, as isa_bn_finalize; scale/shift must equal isa_pro.scale/shift */
+    float* shift;
+    float* mean;               /* may be NULL */
+    float* invstd;             /* may be NULL */
+    float count, momentum, eps;
+    int32_t repeat;            /* as isa_bn_finalize */
+} isa_bn_fin;
+
 typedef struct isa_pro {       /* lazy-input prologue; all pointers may be NULL */
     const float* scale;        /* [c]   ([G][c] for a grouped tensor, see isa_tensor.groups) */
     const float* shift;        /* [c]   */
     const float* bscale;       /* [n,c] per-image channel multiplier (Dropout2d mask, SE gate) */
     int32_t      act;          /* ISA_ACT_* applied after the affine, before bscale */
+    const isa_bn_fin* fin;     /* NULL, or the pending finalize that produces scale/shift (HOST pointer, read during the call) */
 } isa_pro;
 
 typedef struct isa_conv_ep {   /* output epilogue of isa_conv_gemm_ep: y = act(scale[n]*(conv+bias) + shift[n]) + res */
@@ -267,7 +293,7 @@ int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const isa_tensor* 
                  void* stream);
 
 /* ---- squeeze-excite gate + heads (utils.py:402-420, reseg.py:72-75,116-120) ------------------ */
-/* mean over h*w of pro(x): out[n,c] */
+/* mean over h*w of pro(x), ADDED to out[n,c] (float atomics from several workgroups per image): zero it first */
 int isa_chan_mean(const isa_tensor* x, const isa_pro* pro, float* out, void* stream);
 /* gate[n,c] = sigmoid(W2 relu(W1 m + b1) + b2); hidden/intermediates kept for backward */
 int isa_se_fc(const float* mean, const float* w1, const float* b1, const float* w2,

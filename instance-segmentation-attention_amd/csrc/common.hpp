@@ -152,6 +152,88 @@ static inline bool pro_trivial(const ProDev& p) {
     return !p.scale && !p.shift && !p.bscale && p.act == ISA_ACT_NONE;
 }
 
+// ---- BatchNorm finalize, stand-alone (isa_bn_finalize) and inside the consumer of the lazy tensor (isa_pro.fin) ------
+struct FinDev {
+    const float *stats, *gamma, *beta; float *rm, *rv, *scale, *shift, *mean, *invstd;
+    float count, momentum, eps; int repeat;
+};
+static inline FinDev make_fin(const isa_pro* p) {
+    FinDev f{}; f.repeat = 1;
+    if (p && p->fin) {
+        const isa_bn_fin* q = p->fin;
+        f = FinDev{q->stats, q->gamma, q->beta, q->running_mean, q->running_var, q->scale, q->shift, q->mean, q->invstd,
+                   q->count, q->momentum, q->eps, q->repeat < 1 ? 1 : q->repeat};
+    }
+    return f;
+}
+static inline bool fin_valid(const isa_pro* p) {         // scale/shift of the prologue must be the finalize's outputs
+    return !p || !p->fin || (p->fin->stats && p->fin->scale && p->fin->shift && p->fin->scale == p->scale && p->fin->shift == p->shift);
+}
+// stand-alone launch for entry points without the in-kernel form (elementwise.hip)
+int fin_standalone(const isa_pro* p, int c, int groups, hipStream_t s);
+
+// Channel i of a BatchNorm finalize.  all_groups: the memory-writing form (isa_bn_finalize; the writer workgroup of a
+// consumer): groups 0..G-1 in order, scale/shift/mean/invstd [G][c] and the running statistics; else group gsel only,
+// nothing written to memory.  tab (LDS, or NULL): scale -> tab[i], shift -> tab[tab_ld + i] of group gsel.
+// stats == NULL: eval mode, constants from the running statistics (stand-alone only).
+__device__ __forceinline__ void bn_fin_channel(const FinDev& f, int i, int c, int groups, bool all_groups, int gsel,
+                                               float* tab, int tab_ld) {
+    const float g = f.gamma ? f.gamma[i] : 1.f, b = f.beta ? f.beta[i] : 0.f;
+    const bool run = all_groups || !f.stats;
+    float rmi = (run && f.rm) ? f.rm[i] : 0.f, rvi = (run && f.rv) ? f.rv[i] : 0.f;
+    const int g0 = all_groups ? 0 : gsel, g1 = all_groups ? groups : gsel + 1;
+    for (int gi = g0; gi < g1; ++gi) {
+        float mean, var;
+        if (f.stats) {
+            const float* st = f.stats + (long)gi * ISA_STAT_R * 2 * c;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < ISA_STAT_R; ++r) { s1 += st[r * 2 * c + i]; s2 += st[r * 2 * c + c + i]; }
+            mean = s1 / f.count;
+            var = fmaxf(s2 / f.count - mean * mean, 0.f);
+            if (all_groups)
+                for (int k = 0; k < f.repeat; ++k) {
+                    rmi = (1.f - f.momentum) * rmi + f.momentum * mean;
+                    rvi = (1.f - f.momentum) * rvi + f.momentum * var * (f.count / fmaxf(f.count - 1.f, 1.f));
+                }
+        } else {
+            mean = rmi; var = rvi;
+        }
+        const float inv = 1.0f / sqrtf(var + f.eps);
+        const float sc = g * inv, sh = b - mean * g * inv;
+        if (all_groups) {
+            f.scale[gi * c + i] = sc;
+            f.shift[gi * c + i] = sh;
+            if (f.mean) f.mean[gi * c + i] = mean;
+            if (f.invstd) f.invstd[gi * c + i] = inv;
+        }
+        if (tab && gi == gsel) { tab[i] = sc; tab[tab_ld + i] = sh; }
+    }
+    if (all_groups && f.stats) {
+        if (f.rm) f.rm[i] = rmi;
+        if (f.rv) f.rv[i] = rvi;
+    }
+}
+// In a consumer kernel, called by all NTHREADS threads of every workgroup before the prologue constants are read:
+// fills tab[ch - cbeg] / tab[tab_ld + ch - cbeg] (LDS) with scale / shift of this workgroup's statistic group for the
+// channels [cbeg, cbeg + ncb) the workgroup works on; `writer` workgroups (exactly one per channel range of the launch)
+// also write what isa_bn_finalize writes.  Ends with a __syncthreads().  No-op (false) without a pending finalize.
+template <int NTHREADS>
+__device__ __forceinline__ bool bn_fin_inline(const FinDev& f, int c, int groups, int gsel, float* tab, int tab_ld, int tid,
+                                              int cbeg, int ncb, bool writer) {
+    if (!f.stats) return false;
+    for (int i = tid; i < ncb; i += NTHREADS)
+        if (cbeg + i < c) bn_fin_channel(f, cbeg + i, c, groups, writer, gsel, tab - cbeg, tab_ld);
+    __syncthreads();
+    return true;
+}
+template <int NTHREADS>
+__device__ __forceinline__ bool bn_fin_inline(const FinDev& f, int c, int groups, int gsel, float* tab, int tab_ld, int tid) {
+    // the writer is the LAST workgroup in x: in the persistent tile loops it has the fewest tiles, its extra work hides there
+    return bn_fin_inline<NTHREADS>(f, c, groups, gsel, tab, tab_ld, tid, 0, c,
+                                   blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0);
+}
+
 // ---- wave reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

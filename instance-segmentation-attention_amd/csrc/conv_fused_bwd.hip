@@ -348,6 +348,7 @@ extern "C" int isa_conv1x1_bn_backward(const isa_tensor* g, const isa_tensor* y,
                                        const float* w, float* dw, const isa_tensor* dx, int32_t accumulate,
                                        const isa_tensor* addend, float* ws, int64_t ws_floats, isa_slab_arena* defer,
                                        void* stream) {
+    if (xpro && xpro->fin) { if (int rc = fin_standalone(xpro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (g->dtype != ISA_BF16 || y->dtype != ISA_BF16 || x->dtype != ISA_BF16 || dx->dtype != ISA_BF16) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;

@@ -39,6 +39,7 @@ struct GemmParams {
     // optional output epilogue (isa_conv_gemm_ep): y = act(ep_scale[n] * (conv + bias) + ep_shift[n]) + res
     const float *ep_scale, *ep_shift; int ep_act; const void* res; int ldres;
     int G;                                      // statistic groups (1x1 plain only): M, ntiles are per group (common.hpp)
+    FinDev fin;                                 // pending BatchNorm finalize of the lazy input (isa_pro.fin), or stats == NULL
 };
 
 template <typename T> struct Frag;      // 16 contiguous channels of one pixel
@@ -113,8 +114,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
     const int pro_bytes = HAS_PRO ? 2 * p.kp * 4 : 0;
     float* stage = reinterpret_cast<float*>(smem + b_bytes + pro_bytes) + wave * (32 * (NT == 2 ? 65 : 33));
 
+    // A pending finalize of the input's BatchNorm (isa_pro.fin, train mode) runs in this kernel: this group's scale / shift
+    // go straight into the table.  One dword of the cache line of this lane's first fragment is requested ahead of it, so
+    // the round trip to the input overlaps the one to the statistics instead of following it (running the finalize inside
+    // the tile loop, behind the real fragment load, costs these kernels an occupancy step).
+    bool fin_live = false;
+    if constexpr (HAS_PRO && !EP) {
+        if (p.fin.stats != nullptr) {
+            long m = (long)gs.bx * 128 + wave * 32 + r;
+            if (m > p.M - 1) m = p.M - 1;
+            const T* touch = reinterpret_cast<const T*>(p.x) + (IN_MODE == ISA_IN_GATHER2 ? 0 : m * p.ldx + 16 * hh);
+            const unsigned probe = *reinterpret_cast<const unsigned*>(touch);
+            asm volatile("" ::: "memory");                        // keep the request ahead of the finalize
+            bn_fin_inline<256>(p.fin, p.cin, p.G, gs.g, pro_tab, p.kp, tid);
+            asm volatile("" :: "v"(probe));
+            fin_live = true;
+        }
+    }
     if constexpr (HAS_PRO) {
+        const bool fin = fin_live;
         for (int k = tid; k < p.kp; k += 256) {
+            if (fin && k < p.cin) continue;
             float sc = 1.f, sh = 0.f;
             if (k < p.cin) {
                 if (p.pro.scale) sc = p.pro.scale[k];
@@ -489,10 +509,13 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
     const int n0 = tn * BN, K = p.kp;
     const bf16_t* xin = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* wg = reinterpret_cast<const bf16_t*>(p.w);
+    bool fin = false;                                              // pending finalize: see conv_gemm_kernel
+    if constexpr (HAS_PRO && !EP) fin = p.fin.stats != nullptr;
     if constexpr (HAS_PRO) {
         for (int k = tid; k < K; k += 256) {
-            pro_tab[k] = p.pro.scale ? p.pro.scale[k] : 1.f;
-            pro_tab[K + k] = p.pro.shift ? p.pro.shift[k] : 0.f;
+            if (fin && k < p.cin) continue;
+            pro_tab[k] = (!fin && p.pro.scale) ? p.pro.scale[k] : 1.f;
+            pro_tab[K + k] = (!fin && p.pro.shift) ? p.pro.shift[k] : 0.f;
         }
     }
     // staging: thread -> rows srow + 32 i, 8 contraction elements at sseg
@@ -505,6 +528,16 @@ __global__ __launch_bounds__(256) void conv_gemm_tiled_kernel(GemmParams p) {
         if (m > p.M - 1) m = p.M - 1;                              // rows >= M read the last valid row; the epilogue masks them
         aoff[i] = m * p.ldx + sseg;
         bsrow[i] = (HAS_PRO && p.pro.bscale) ? p.pro.bscale + (m / ((long)p.mh * p.mw)) * p.cin + sseg : nullptr;
+    }
+    if constexpr (HAS_PRO && !EP) {
+        if (fin) {                                                 // see conv_gemm_kernel: touch the first tile's rows, finalize
+            unsigned probe[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) probe[i] = *reinterpret_cast<const unsigned*>(xin + aoff[i]);
+            asm volatile("" ::: "memory");
+            bn_fin_inline<256>(p.fin, p.cin, p.G, gs.g, pro_tab, K, tid);
+            asm volatile("" :: "v"(probe[0]), "v"(probe[1]), "v"(probe[2]), "v"(probe[3]));
+        }
     }
     // two register sets: the loads of K tile kt + 2 are issued while tile kt is multiplied and tile kt + 1 is written
     // to LDS - with one workgroup per CU on these small problems nothing else covers the memory latency
@@ -845,6 +878,11 @@ static int conv_gemm_impl(const isa_tensor* x, const isa_pro* pro, const void* w
     if (G > 1 && (stats || (pro && (pro->scale || pro->shift)))) {
         if (in_mode != ISA_IN_1X1 || out_mode != ISA_OUT_PLAIN || ep || x->n % G || tensor_groups(y) != G) return ISA_EINVAL;
         p.G = G; p.M /= G;
+    }
+    if (pro && pro->fin) {
+        if (!fin_valid(pro)) return ISA_EINVAL;
+        if (!ep) p.fin = make_fin(pro);
+        else if (int rc = fin_standalone(pro, x->c, G, as_stream(stream))) return rc;
     }
     if (!ep && in_mode == ISA_IN_3X3 && out_mode == ISA_OUT_PLAIN && x->dtype == ISA_BF16 && !has_pro && !stats && kp == 32 &&
         y->c <= 32)

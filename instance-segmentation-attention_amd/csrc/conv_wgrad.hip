@@ -621,6 +621,7 @@ extern "C" int isa_conv_wgrad(const isa_tensor* x, const isa_pro* pro, const isa
                               float* dw, float* dbias, int32_t in_mode, int32_t out_mode,
                               const int32_t* kmap, int32_t ksrc, float* ws, int64_t ws_floats,
                               isa_slab_arena* defer, void* stream) {
+    if (pro && pro->fin) { if (int rc = fin_standalone(pro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype || (!ws && !defer)) return ISA_EINVAL;
     if (in_mode == ISA_IN_GATHER2) return ISA_EINVAL;
     WgParams p{};

@@ -309,6 +309,7 @@ int dw_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const flo
     // input lives in 24-channel rows; pad lanes compute garbage that no consumer reads and no statistic sees)
     const int c8 = (x->c + 7) / 8 * 8;
     if (x->ld >= c8 && y->ld >= c8) return dw2_forward(x, pro, w, bias, y, stats, accumulate, stream);
+    if (pro && pro->fin) { if (int rc = fin_standalone(pro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     DwParams p{};
     p.x = x->data; p.w = w; p.bias = bias; p.y = y->data;
     p.n = x->n; p.h = x->h; p.w_ = x->w; p.c = x->c; p.ldx = x->ld; p.ldy = y->ld;
@@ -356,6 +357,7 @@ extern "C" int isa_dwconv3x3_dgrad(const isa_tensor* dy, const void* w, const is
 extern "C" int isa_dwconv3x3_wgrad(const isa_tensor* x, const isa_pro* pro, const isa_tensor* dy,
                                    float* dw, float* dbias, int32_t csrc, float* ws, int64_t ws_floats, isa_slab_arena* defer,
                                    void* stream) {
+    if (pro && pro->fin) { if (int rc = fin_standalone(pro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     if (!tensor_ok(x, 8) || !tensor_ok(dy, 8) || !dw || x->dtype != dy->dtype) return ISA_EINVAL;
     if (x->n != dy->n || x->h != dy->h || x->w != dy->w || x->c != dy->c) return ISA_EINVAL;
     if (!ws && !defer) return ISA_EINVAL;

@@ -34,6 +34,7 @@ struct Dw2Params {
     int tiles_x, tiles_y; long ntiles;
     float* ws; int csrc;
     int G;                       // statistic groups: n and ntiles are per group (common.hpp)
+    FinDev fin;                  // pending BatchNorm finalize of the lazy input (forward only), or stats == NULL
 };
 
 // 8 storage elements kept packed in registers (4 VGPRs for bf16) until they are consumed
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
     float* tile_base = sm;                          // [NBUF][HALO][PS]
     float* wts = sm + NBUF * HALO * PS;             // [9][CB]
     float* red = wts + 9 * CB;                      // [2*CB]
+    float* fin_tab = red + 2 * CB;                  // [2][CB] scale / shift of this channel block when the finalize runs here
     const int tid = threadIdx.x;
     const bool loader = DB && tid >= 256;
     const int ltid = loader ? tid - 256 : tid;        // index inside the role group
@@ -207,12 +209,16 @@ __global__ __launch_bounds__(DB ? 768 : 256) __attribute__((amdgpu_waves_per_eu(
 
     // per-channel prologue constants: loaded ONCE per lane (they were re-read from global memory at the top of every
     // tile: a dependent round trip ahead of the tile's own loads); only the per-image scale changes with the tile
+    // a pending finalize of the input's BatchNorm runs here, for this workgroup's 32 channels; the last workgroup of
+    // each channel block writes the arrays the backward pass reads
+    const bool fin = HAS_PRO && bn_fin_inline<NTHR>(p.fin, p.c, p.G, gs.g, fin_tab, CB, tid, c_base, CB,
+                                                    blockIdx.x == gridDim.x - 1 && blockIdx.z == 0);
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = min(c0 + j, p.c - 1);
-        sc[j] = (HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f;
-        sh[j] = (HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f;
+        sc[j] = fin ? fin_tab[c - c_base] : ((HAS_PRO && p.pro.scale) ? p.pro.scale[c] : 1.f);
+        sh[j] = fin ? fin_tab[CB + c - c_base] : ((HAS_PRO && p.pro.shift) ? p.pro.shift[c] : 0.f);
     }
     // tile-invariant part of the staging addresses: halo pixel (rr, cc) of slot `it` and its element offset from the
     // tile's halo origin; per tile only a scalar base pointer and (on border tiles) four scalar bounds remain
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void dw2_wgrad_reduce_kernel(const float* ws, 
 template <typename T, bool HAS_PRO, int ACT>
 int launch_fwd2_inst(Dw2Params& p, dim3 grid, hipStream_t s) {
     constexpr bool DB = sizeof(T) == 2;
-    constexpr size_t lds = ((size_t)(DB ? 2 : 1) * HALO * PS + 9 * CB + 2 * CB) * 4;
+    constexpr size_t lds = ((size_t)(DB ? 2 : 1) * HALO * PS + 9 * CB + 2 * CB + 2 * CB) * 4;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_fwd_kernel<T, HAS_PRO, ACT, DB>),
@@ -1017,6 +1023,10 @@ int dw2_forward(const isa_tensor* x, const isa_pro* pro, const void* w, const fl
         if (x->n % G || tensor_groups(y) != G) return ISA_EINVAL;
         p.G = G; p.n = x->n / G;
     }
+    if (pro && pro->fin) {
+        if (!fin_valid(pro)) return ISA_EINVAL;
+        p.fin = make_fin(pro);
+    }
     if (x->dtype == ISA_BF16) return launch_fwd2<bf16_t>(p, has_pro, as_stream(stream));
     return launch_fwd2<float>(p, has_pro, as_stream(stream));
 }
@@ -1044,6 +1054,7 @@ extern "C" int isa_dwconv3x3_bn_backward(const isa_tensor* g, const isa_tensor* 
                                          const void* w_flipped, float* dw, int32_t csrc,
                                          const isa_tensor* dx, int32_t accumulate, const isa_tensor* addend,
                                          float* ws, int64_t ws_floats, isa_slab_arena* defer, void* stream) {
+    if (xpro && xpro->fin) { if (int rc = fin_standalone(xpro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     if (!tensor_ok(g, 8) || !tensor_ok(y, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8)) return ISA_EINVAL;
     if (!ybn || !ybn->scale || !ybn->shift || !ybn->mean || !ybn->invstd || !ybn->red || !(ybn->count > 0)) return ISA_EINVAL;
     if (!w_flipped || !dw || (!ws && !defer)) return ISA_EINVAL;

@@ -62,39 +62,9 @@ __global__ void pack_kernel(const isa_pack_entry* tab, const int32_t* kmap, cons
 // groups > 1: stats [G][R][2c] -> scale/shift/mean/invstd [G][c]; the running statistics take the G updates in group
 // order (the reference runs the groups - its decoder iterations - one after the other through the same module);
 // repeat > 1: the same update applied `repeat` times (a layer whose identical forward the reference runs `repeat` times).
-__global__ void bn_finalize_kernel(const float* stats, float count, const float* gamma,
-                                   const float* beta, float* rm, float* rv, float momentum, float eps,
-                                   float* scale, float* shift, float* mean_o, float* invstd_o, int c, int groups, int repeat) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
-        const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
-        float rmi = rm ? rm[i] : 0.f, rvi = rv ? rv[i] : 0.f;
-        for (int gi = 0; gi < groups; ++gi) {
-            float mean, var;
-            if (stats) {
-                const float* st = stats + (long)gi * ISA_STAT_R * 2 * c;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < ISA_STAT_R; ++r) { s1 += st[r * 2 * c + i]; s2 += st[r * 2 * c + c + i]; }
-                mean = s1 / count;
-                var = fmaxf(s2 / count - mean * mean, 0.f);
-                for (int k = 0; k < repeat; ++k) {
-                    rmi = (1.f - momentum) * rmi + momentum * mean;
-                    rvi = (1.f - momentum) * rvi + momentum * var * (count / fmaxf(count - 1.f, 1.f));
-                }
-            } else {
-                mean = rmi; var = rvi;
-            }
-            const float inv = 1.0f / sqrtf(var + eps);
-            scale[gi * c + i] = g * inv;
-            shift[gi * c + i] = b - mean * g * inv;
-            if (mean_o) mean_o[gi * c + i] = mean;
-            if (invstd_o) invstd_o[gi * c + i] = inv;
-        }
-        if (stats) {
-            if (rm) rm[i] = rmi;
-            if (rv) rv[i] = rvi;
-        }
-    }
+__global__ void bn_finalize_kernel(FinDev f, int c, int groups) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x)
+        bn_fin_channel(f, i, c, groups, true, 0, nullptr, 0);
 }
 
 // Ordered running-statistics updates of many train-mode BatchNorm layers in one launch (isa_bn_running_update):
@@ -249,10 +219,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p, Walk wk) {
 // out = (pro(x) (+ res) (+ res2)) * oscale[b,c]
 // groups (blockIdx.z): pixels / wk.pixels are per group.  bcast: x (and res) hold ONE group of images that every output
 // group reads (an identical sub-network evaluated once for all decoder iterations; only the per-image oscale differs).
-struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; int groups, bcast; };
+struct MatParams { View x, res, res2, out; ProDev pro; const float* oscale; long pixels; int cg; int has_res, has_res2; int groups, bcast; FinDev fin; };
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) {
     const int C = p.x.c;
+    // a pending finalize of x's BatchNorm runs here (isa_pro.fin): x's statistic group of this workgroup into LDS
+    __shared__ float fin_tab[2 * ISA_FIN_MAX_C];
+    const bool fin = bn_fin_inline<256>(p.fin, C, p.bcast ? 1 : p.groups, p.bcast ? 0 : (int)blockIdx.z, fin_tab, ISA_FIN_MAX_C,
+                                        threadIdx.x);
     if (p.groups > 1 && blockIdx.z) {
         const long g = blockIdx.z, gp = g * wk.pixels;
         const long gimg = g * (wk.pixels / ((long)p.x.h * p.x.w)) * C;
@@ -276,8 +250,8 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatParams p, Walk wk) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = min(c0 + j, C - 1);
-            sc[j] = p.pro.scale ? p.pro.scale[c] : 1.f;
-            sh[j] = p.pro.shift ? p.pro.shift[c] : 0.f;
+            sc[j] = fin ? fin_tab[c] : (p.pro.scale ? p.pro.scale[c] : 1.f);
+            sh[j] = fin ? fin_tab[ISA_FIN_MAX_C + c] : (p.pro.shift ? p.pro.shift[c] : 0.f);
         }
         const bool per_image = p.pro.bscale || p.oscale;
         const long step = (long)gridDim.x * ppb;
@@ -635,8 +609,15 @@ extern "C" int isa_bn_finalize(const float* stats, float count, const float* gam
     if (groups < 1) groups = 1;
     if (repeat < 1) repeat = 1;
     if (!stats && groups != 1) return ISA_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), stats, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, c, groups, repeat);
+    const FinDev f{stats, gamma, beta, running_mean, running_var, scale, shift, mean, invstd, count, momentum, eps, repeat};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), f, c, groups);
+    return launch_status();
+}
+
+int fin_standalone(const isa_pro* p, int c, int groups, hipStream_t s) {
+    if (!p || !p->fin) return ISA_OK;
+    if (!fin_valid(p) || c <= 0) return ISA_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, s, make_fin(p), c, groups < 1 ? 1 : groups);
     return launch_status();
 }
 
@@ -748,6 +729,11 @@ extern "C" int isa_affine_act_res(const isa_tensor* x, const isa_pro* pro, const
     if (res) p.res = mkview(res);
     if (res2) p.res2 = mkview(res2);
     p.groups = G; p.bcast = bcast;
+    if (pro && pro->fin) {
+        if (!fin_valid(pro) || (!bcast && tensor_groups(x) != G)) return ISA_EINVAL;
+        if (x->c <= ISA_FIN_MAX_C) p.fin = make_fin(pro);
+        else if (int rc = fin_standalone(pro, x->c, tensor_groups(x), as_stream(stream))) return rc;
+    }
     p.pixels = (long)(out->n / G) * x->h * x->w; p.cg = (x->c + 7) / 8;       // per group
     if (p.pixels * G >= (1L << 32)) return ISA_EINVAL;
     const Walk wk = mkwalk(x->c, p.pixels);
@@ -838,6 +824,7 @@ extern "C" int isa_avgpool3(const isa_tensor* x, const isa_tensor* mask, const i
 }
 
 extern "C" int isa_chan_mean(const isa_tensor* x, const isa_pro* pro, float* out, void* stream) {
+    if (pro && pro->fin) { if (int rc = fin_standalone(pro, x->c, tensor_groups(x), as_stream(stream))) return rc; }   // no in-kernel form here
     if (!tensor_ok(x, 8) || x->c % 8 || !out) return ISA_EINVAL;
     MeanParams p{mkview(x), make_pro(pro), out, 1.f / ((float)x->h * x->w)};
     const long items = (long)x->h * x->w * (x->c / 8);

@@ -26,16 +26,76 @@ def rup(x, m):
     return (x + m - 1) // m * m
 
 
-class Pro:
-    """Lazy prologue: value = act(scale*raw + shift) * bscale."""
-    __slots__ = ("scale", "shift", "bscale", "act", "_c")
+class PendingFin:
+    """A train-mode BatchNorm finalize that has not been launched (isa_bn_fin, include/isa_kernels.h): the first consumer
+    of the lazy tensor on each stream either runs it inside its own kernel (`inline`: isa_conv_gemm, isa_dwconv3x3,
+    isa_affine_act_res) or launches isa_bn_finalize ahead of itself (`resolve`: everything else that reads the scale /
+    shift arrays).  Exactly one of them carries the running-statistics update.  Consumers on a stream that has already
+    seen one are ordered behind it and read the arrays.  Every consumer recomputes identical values from the same sums,
+    so consumers on different streams need no edge between them."""
+    __slots__ = ("eng", "stats", "count", "pre", "c", "scale", "shift", "mean", "invstd", "groups", "rep", "running_taken",
+                 "done", "keep")
 
-    def __init__(self, scale=None, shift=None, act=L.ACT_NONE, bscale=None):
-        self.scale, self.shift, self.act, self.bscale = scale, shift, act, bscale
-        self._c = L.IsaPro(L.ptr(scale), L.ptr(shift), L.ptr(bscale), act)
+    def __init__(self, eng, stats, count, pre, c, scale, shift, mean, invstd, groups, rep, running_taken):
+        self.eng, self.stats, self.count, self.pre, self.c = eng, stats, count, pre, c
+        self.scale, self.shift, self.mean, self.invstd, self.groups, self.rep = scale, shift, mean, invstd, groups, rep
+        self.running_taken = running_taken
+        self.done, self.keep = set(), []
+
+    def _running(self):
+        if self.running_taken:
+            return None, None
+        self.running_taken = True
+        P = self.eng.params
+        return P.ptr(self.pre + ".running_mean"), P.ptr(self.pre + ".running_var")
+
+    def settled(self):
+        E = self.eng
+        return E._deferring or E.cur in self.done
+
+    def resolve(self):
+        if self.settled():
+            return
+        E, P = self.eng, self.eng.params
+        rm, rv = self._running()
+        L.check(E.lib.isa_bn_finalize(L.ptr(self.stats), self.count, P.ptr(self.pre + ".weight"), P.ptr(self.pre + ".bias"),
+                                      rm, rv, E.BN_MOMENTUM, E.BN_EPS, L.ptr(self.scale), L.ptr(self.shift),
+                                      L.ptr(self.mean), L.ptr(self.invstd), self.c, self.groups, self.rep, E.st()),
+                "isa_bn_finalize")
+        self.done.add(E.cur)
+
+    def inline(self, pro):
+        """isa_pro* carrying this finalize for a consumer with the in-kernel form."""
+        E, P = self.eng, self.eng.params
+        rm, rv = self._running()
+        a = lambda v: v.value if v is not None else None
+        d = L.IsaBnFin(self.stats.data_ptr(), a(P.ptr(self.pre + ".weight")), a(P.ptr(self.pre + ".bias")), a(rm), a(rv),
+                       self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
+                       self.count, E.BN_MOMENTUM, E.BN_EPS, self.rep)
+        pc = L.IsaPro(L.ptr(pro.scale), L.ptr(pro.shift), L.ptr(pro.bscale), pro.act, C.pointer(d))
+        self.keep.append((d, pc))
+        self.done.add(E.cur)
+        return C.byref(pc)
+
+
+class Pro:
+    """Lazy prologue: value = act(scale*raw + shift) * bscale.  `fin`: the BatchNorm finalize that fills scale / shift is
+    still pending (PendingFin) - c() launches it if this stream has not seen it, c_fin() hands it to the consumer."""
+    __slots__ = ("scale", "shift", "bscale", "act", "_c", "fin")
+
+    def __init__(self, scale=None, shift=None, act=L.ACT_NONE, bscale=None, fin=None):
+        self.scale, self.shift, self.act, self.bscale, self.fin = scale, shift, act, bscale, fin
+        self._c = L.IsaPro(L.ptr(scale), L.ptr(shift), L.ptr(bscale), act, None)
 
     def c(self):
+        if self.fin is not None:
+            self.fin.resolve()
         return C.byref(self._c)
+
+    def c_fin(self):
+        if self.fin is None or self.fin.settled():
+            return C.byref(self._c)
+        return self.fin.inline(self)
 
 
 class Act:
@@ -68,6 +128,10 @@ class Act:
 
     def p(self):
         return self.pro.c() if self.pro is not None else None
+
+    def p_fin(self):
+        """p() for the entry points that can run a pending BatchNorm finalize themselves."""
+        return self.pro.c_fin() if self.pro is not None else None
 
     def slice(self, c0, c, pro=None):
         return Act(self.buf, self.c0 + c0, c, pro, self.needs_grad, self.groups)
@@ -495,6 +559,8 @@ class Engine:
         self.fuse_eval = os.environ.get("ISA_FUSE_EVAL", "1") != "0"
         # ... and a whole InvertedV1Residual block in one launch where the shape allows (isa_dwpw_eval)
         self.fuse_block = os.environ.get("ISA_FUSE_BLOCK", "1") != "0"
+        # train-mode BatchNorm finalizes run inside the consumer of the lazy tensor (PendingFin); 0: one launch each
+        self.inline_fin = os.environ.get("ISA_INLINE_FIN", "1") != "0"
         self._pw_out: Dict[tuple, dict] = {}
         self._pw_in: Dict[tuple, dict] = {}      # conv input -> the same records: residual gradients ride along
         # eval-mode BN constants per layer: persistent buffers (a captured inference graph reads them), recomputed in
@@ -617,18 +683,25 @@ class Engine:
         self.bn_running_queue = []
 
     def _finalize_train(self, stats, count, pre, c, scale, shift, mean, invstd, groups=1):
+        """Train-mode finalize of one BatchNorm.  With inline_fin (default) nothing is launched here: the PendingFin that is
+        returned travels with the lazy tensor and its first consumer does the work (see PendingFin)."""
         P = self.params
         defer = self.defer_bn_running
         rep = self.bn_repeat
         assert not (defer and (groups > 1 or rep > 1)), "deferred running statistics are a single-group mechanism"
-        L.check(self.lib.isa_bn_finalize(L.ptr(stats), count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
-                                         None if defer else P.ptr(pre + ".running_mean"),
-                                         None if defer else P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
-                                         L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, groups, rep, self.st()),
-                "isa_bn_finalize")
+        fin = None
+        if self.inline_fin:
+            fin = PendingFin(self, stats, count, pre, c, scale, shift, mean, invstd, groups, rep, running_taken=defer)
+        else:
+            L.check(self.lib.isa_bn_finalize(L.ptr(stats), count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
+                                             None if defer else P.ptr(pre + ".running_mean"),
+                                             None if defer else P.ptr(pre + ".running_var"), self.BN_MOMENTUM, self.BN_EPS,
+                                             L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), c, groups, rep, self.st()),
+                    "isa_bn_finalize")
         if defer:
             self.bn_running_queue.append((stats, count, pre, c))
         P.int_buffers[pre + ".num_batches_tracked"] += groups * rep
+        return fin
 
     def defer_handle(self):
         """isa_slab_arena* for the weight-gradient entry points while a backward pass runs, else NULL."""
@@ -876,7 +949,7 @@ class Engine:
         if self.profile:     # algorithmic bytes: input read once + output written once
             esz = x.buf.element_size()
             self.next_bytes = (x.n * x.h * x.w * x.c + out.n * out.h * out.w * out.c) * esz
-        L.check(self.lib.isa_conv_gemm(x.d(), x.p(), self.packer.ptr(reg["fwd"]), reg["kp"],
+        L.check(self.lib.isa_conv_gemm(x.d(), x.p_fin(), self.packer.ptr(reg["fwd"]), reg["kp"],
                                        self.params.ptr(bias) if bias else None, out.d(), in_mode, out_mode,
                                        L.ptr(st), 0, self.st()), "isa_conv_gemm")
 
@@ -894,7 +967,7 @@ class Engine:
         st = self.scratch(2 * out.c * STAT_R * out.groups) if stats else None
         if self.profile:
             self.next_bytes = 2 * x.n * x.h * x.w * x.c * x.buf.element_size()
-        L.check(self.lib.isa_dwconv3x3(x.d(), x.p(), self.packer.ptr(reg["fwd"]),
+        L.check(self.lib.isa_dwconv3x3(x.d(), x.p_fin(), self.packer.ptr(reg["fwd"]),
                                        self.params.ptr(bias) if bias else None, out.d(), L.ptr(st), self.st()),
                 "isa_dwconv3x3")
         if self.record:
@@ -973,8 +1046,9 @@ class Engine:
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
+        fin = None
         if train:
-            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
+            fin = self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
         elif cached is None:
             L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
@@ -983,7 +1057,7 @@ class Engine:
             self._eval_bn_filled(pre)
         else:
             self._eval_bn_wait(pre)
-        lazy = raw.with_pro(Pro(scale, shift, act))
+        lazy = raw.with_pro(Pro(scale, shift, act, fin=fin))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
         if self.record:
@@ -1050,8 +1124,9 @@ class Engine:
         else:       # eval: constants of the running statistics, computed once per weight version
             scale, shift, mean, invstd = (torch.empty(c, dtype=torch.float32, device=self.device) for _ in range(4))
             self.eval_bn_cache[pre] = (scale, shift, mean, invstd)
+        fin = None
         if train:
-            self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
+            fin = self._finalize_train(stats, count, pre, c, scale, shift, mean, invstd, G)
         elif cached is None:
             L.check(self.lib.isa_bn_finalize(None, count, P.ptr(pre + ".weight"), P.ptr(pre + ".bias"),
                                              P.ptr(pre + ".running_mean"), P.ptr(pre + ".running_var"),
@@ -1060,12 +1135,12 @@ class Engine:
             self._eval_bn_filled(pre)
         else:
             self._eval_bn_wait(pre)
-        lazy = raw.with_pro(Pro(scale, shift, act, bscale))
+        lazy = raw.with_pro(Pro(scale, shift, act, bscale, fin=fin))
         lazy.bn = dict(pre=pre, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
                        train=train, raw=raw)
         if self.profile:
             self.next_bytes = (2 + (res is not None) + (res2 is not None)) * raw.n * raw.h * raw.w * raw.c * raw.buf.element_size()
-        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p(), res.d() if res is not None else None,
+        L.check(self.lib.isa_affine_act_res(lazy.d(), lazy.p_fin(), res.d() if res is not None else None,
                                             res2.d() if res2 is not None else None, L.ptr(oscale), out.d(),
                                             self.st()), "isa_affine_act_res")
         if self.record:

@@ -25,9 +25,16 @@ class IsaTensor(C.Structure):
                 ("c", C.c_int32), ("ld", C.c_int32), ("dtype", C.c_int32), ("groups", C.c_int32)]
 
 
+class IsaBnFin(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("count", C.c_float), ("momentum", C.c_float), ("eps", C.c_float),
+                ("repeat", C.c_int32)]
+
+
 class IsaPro(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("bscale", C.c_void_p),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("fin", C.POINTER(IsaBnFin))]
 
 
 class IsaConvEp(C.Structure):
