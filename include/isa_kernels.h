@@ -307,9 +307,14 @@ int isa_chan_argmax(const isa_tensor* x, const isa_tensor* y, void* stream);
  * SpatialAttentionLayer (utils.py:484-523), four steps: */
 int isa_mask_dot(const isa_tensor* x, const float* m, const float* w, const float* bias,
                  float* dot /*zeroed*/, float* chansum /*[n,c] zeroed*/, void* stream);
+/* `part` (isa_sp_softmax, isa_ins_softmax): caller scratch of n * ISA_ROW_CHUNKS * 4 floats, or NULL.  With it (and
+ * L <= 4096 * ISA_ROW_CHUNKS) a row is worked on by L / 4096 workgroups in two launches - chunk scores and online-softmax
+ * partials, then the normalisation - instead of by one workgroup per row (n = 16 ... 32 rows of 65 536 pixels left most of the
+ * chip idle for 86 us); same values up to the order of the fp32 sums. */
+#define ISA_ROW_CHUNKS 64
 int isa_sp_softmax(const float* dot, const float* m, const float* chansum, const float* lh,
                    const float* fcw, const float* fcb, int32_t n, int32_t c, int64_t L,
-                   float* beta, float* rowstat /*[n,4]: max,sumexp,count,h_t*/, void* stream);
+                   float* beta, float* rowstat /*[n,4]: max,sumexp,count,h_t*/, float* part, void* stream);
 int isa_scaled_stats(const isa_tensor* x, const float* beta, float* stats /*[2c] zeroed*/, void* stream);
 int isa_sp_apply(const isa_tensor* x, const float* beta, const float* m, const float* scale,
                  const float* shift, const isa_tensor* out, void* stream);
@@ -322,7 +327,7 @@ int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, const float* me
 /* HardAttentionLayer softmax for the selected instance of each image (utils.py:648-655 + the
  * gather of attenet2.py:342-343): alpha[b,:] = softmax over pixels of ins[b, idx[b]] */
 int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
-                    int64_t L, float* alpha, float* rowstat /*[n,2]*/, int32_t nsrc, void* stream);
+                    int64_t L, float* alpha, float* rowstat /*[n,2]*/, int32_t nsrc, float* part, void* stream);
 /* `nsrc` (here and in isa_pool_target / isa_ins_softmax_bwd; 0 = n): the n rows are n/nsrc decoder iterations over the same
  * nsrc images - row b reads merge / ins of image b % nsrc with its own idx[b], so the fronts of all iterations
  * (attenet2.py:384-399) are one launch.  isa_concat_aux's `mask_n` is the same for its shared mask_all map. */

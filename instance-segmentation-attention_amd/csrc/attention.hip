@@ -296,6 +296,90 @@ __global__ __launch_bounds__(1024) void ins_softmax_kernel(const float* merge, c
     if (threadIdx.x == 0 && rowstat) { rowstat[2 * b] = mx; rowstat[2 * b + 1] = se; }
 }
 
+// ---- chunked row softmax (a7 step 2 and a9/a10 with many workgroups per row) ---------------------------------------
+// One 1024-thread workgroup per row keeps n of the 256 CUs busy for 86 us (n = 16 ... 32 rows of 65 536 pixels).  Here a
+// row is cut into S chunks of <= 4096 pixels, one 256-thread workgroup each:
+//   pass 1 (row_score_kernel): the masked score z of the chunk (16 values per thread, kept in registers), parked in the
+//           output row (-inf outside the mask), and the chunk's online-softmax partials part[b][s] = {max, sum exp(z - max), count};
+//   pass 2 (row_norm_kernel):  row max / sum from the S partials (sum_s e_s exp(m_s - max)), then the chunk is normalised
+//           in place; chunk 0 writes rowstat.
+// MODE 0: beta = count * softmax(fcw tanh(dot + ht) + fcb) over m >= 0.5 (SpatialAttentionLayer);  MODE 1: alpha = softmax
+// of merge over the pixels of instance idx[b] (HardAttentionLayer).  Same values as the one-workgroup kernels up to the
+// order of the fp32 sums.
+constexpr int ROW_CHUNK = 4096, ROW_MAX_CHUNKS = ISA_ROW_CHUNKS;
+struct RowScore {
+    const float *dot, *m, *chansum, *lh, *fcw, *fcb; int C;                 // MODE 0
+    const float* merge; const int64_t* ins; const int32_t* idx; int nobj, nsrc;   // MODE 1
+    long L; int S; float* out; float* part; float* rowstat;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void row_score_kernel(RowScore q) {
+    __shared__ float sh[4];
+    __shared__ float s_ht;
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const long p0 = (long)s * ROW_CHUNK, p1 = min(q.L, p0 + ROW_CHUNK);
+    float ht = 0.f, fw = 0.f, fb = 0.f;
+    const float *src0 = nullptr, *msk = nullptr; const int64_t* plane = nullptr;
+    if constexpr (MODE == 0) {
+        if (tid < 64) {
+            float a = 0.f;
+            for (int c = tid; c < q.C; c += 64) a += q.lh[c] * q.chansum[(long)b * q.C + c];
+            a = wave_sum(a);
+            if (tid == 0) s_ht = a / (float)q.L;
+        }
+        __syncthreads();
+        ht = s_ht; fw = q.fcw[0]; fb = q.fcb[0];
+        src0 = q.dot + (long)b * q.L; msk = q.m + (long)b * q.L;
+        if (s == 0 && tid == 0 && q.rowstat) q.rowstat[4 * b + 3] = ht;
+    } else {
+        const int bi = b % q.nsrc;
+        plane = q.ins + ((long)bi * q.nobj + q.idx[b]) * q.L;
+        src0 = q.merge + (long)bi * q.L;
+    }
+    float* o = q.out + (long)b * q.L;
+    float z[ROW_CHUNK / 256];
+    float mx = -INFINITY, cnt = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_CHUNK / 256; ++i) {
+        const long p = p0 + tid + 256 * i;
+        float v = -INFINITY;
+        if (p < p1) {
+            if constexpr (MODE == 0) { if (msk[p] >= 0.5f) { v = fmaf(fw, tanhf(src0[p] + ht), fb); cnt += 1.f; } }
+            else { if (plane[p] != 0) v = src0[p]; }
+            o[p] = v;
+        }
+        z[i] = v; mx = fmaxf(mx, v);
+    }
+    mx = block_max(mx, sh);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_CHUNK / 256; ++i) if (z[i] != -INFINITY) se += expf(z[i] - mx);
+    se = block_sum(se, sh);
+    if constexpr (MODE == 0) cnt = block_sum(cnt, sh);
+    if (tid == 0) { float* pt = q.part + ((long)b * q.S + s) * 4; pt[0] = mx; pt[1] = se; pt[2] = cnt; }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void row_norm_kernel(float* out, const float* part, int S, long L, float* rowstat) {
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // every thread folds the S <= 64 partials itself (the same values in the same order in every workgroup of the row)
+    float mx = -INFINITY;
+    for (int i = 0; i < S; ++i) mx = fmaxf(mx, part[((long)b * S + i) * 4]);
+    float se = 0.f, cnt = 0.f;
+    for (int i = 0; i < S; ++i) {
+        const float* pt = part + ((long)b * S + i) * 4;
+        if (pt[0] != -INFINITY) se += pt[1] * expf(pt[0] - mx);
+        cnt += pt[2];
+    }
+    const float k = MODE == 0 ? (cnt > 0.f ? cnt / se : 0.f) : (se > 0.f ? 1.f / se : 0.f);
+    float* o = out + (long)b * L;
+    const long p0 = (long)s * ROW_CHUNK, p1 = min(L, p0 + ROW_CHUNK);
+    for (long p = p0 + tid; p < p1; p += 256) { const float z = o[p]; o[p] = z != -INFINITY ? k * expf(z - mx) : 0.f; }
+    if (s == 0 && tid == 0 && rowstat) {
+        if (MODE == 0) { rowstat[4 * b] = mx; rowstat[4 * b + 1] = se; rowstat[4 * b + 2] = cnt; }
+        else { rowstat[2 * b] = mx; rowstat[2 * b + 1] = se; }
+    }
+}
+
 // ---- a11: s_t[b] = argmax_p alpha[b,p], first maximum wins (torch.argmax) -------------------------
 // `race` (optional): the exponential race of DecoderLayer.sample's training branch - argmax_p alpha[p] / race[p] with
 // race ~ Exp(1) draws one index from Multinomial(alpha) (torch.multinomial's own single-sample form, attenet2.py:321)
@@ -457,8 +541,17 @@ extern "C" int isa_mask_dot(const isa_tensor* x, const float* m, const float* w,
 
 extern "C" int isa_sp_softmax(const float* dot, const float* m, const float* chansum, const float* lh,
                               const float* fcw, const float* fcb, int32_t n, int32_t c, int64_t L,
-                              float* beta, float* rowstat, void* stream) {
+                              float* beta, float* rowstat, float* part, void* stream) {
     if (!dot || !m || !chansum || !lh || !fcw || !fcb || !beta || n <= 0 || L <= 0) return ISA_EINVAL;
+    const long S = (L + ROW_CHUNK - 1) / ROW_CHUNK;
+    if (part && S <= ROW_MAX_CHUNKS) {
+        RowScore q{};
+        q.dot = dot; q.m = m; q.chansum = chansum; q.lh = lh; q.fcw = fcw; q.fcb = fcb; q.C = c;
+        q.L = L; q.S = (int)S; q.out = beta; q.part = part; q.rowstat = rowstat;
+        hipLaunchKernelGGL(row_score_kernel<0>, dim3((unsigned)S, n), dim3(256), 0, as_stream(stream), q);
+        hipLaunchKernelGGL(row_norm_kernel<0>, dim3((unsigned)S, n), dim3(256), 0, as_stream(stream), beta, part, (int)S, (long)L, rowstat);
+        return launch_status();
+    }
     hipLaunchKernelGGL(sp_softmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), dot, m, chansum, lh, fcw, fcb,
                        c, (long)L, beta, rowstat);
     return launch_status();
@@ -514,10 +607,19 @@ extern "C" int isa_maskbn_apply_pool(const isa_tensor* e, const float* sem, cons
 }
 
 extern "C" int isa_ins_softmax(const float* merge, const int64_t* ins, const int32_t* idx, int32_t n, int32_t nobj,
-                               int64_t L, float* alpha, float* rowstat, int32_t nsrc, void* stream) {
+                               int64_t L, float* alpha, float* rowstat, int32_t nsrc, float* part, void* stream) {
     if (!merge || !ins || !idx || !alpha || n <= 0) return ISA_EINVAL;
     if (nsrc <= 0) nsrc = n;
     if (n % nsrc) return ISA_EINVAL;
+    const long S = (L + ROW_CHUNK - 1) / ROW_CHUNK;
+    if (part && S <= ROW_MAX_CHUNKS) {
+        RowScore q{};
+        q.merge = merge; q.ins = ins; q.idx = idx; q.nobj = nobj; q.nsrc = nsrc;
+        q.L = L; q.S = (int)S; q.out = alpha; q.part = part; q.rowstat = rowstat;
+        hipLaunchKernelGGL(row_score_kernel<1>, dim3((unsigned)S, n), dim3(256), 0, as_stream(stream), q);
+        hipLaunchKernelGGL(row_norm_kernel<1>, dim3((unsigned)S, n), dim3(256), 0, as_stream(stream), alpha, part, (int)S, (long)L, rowstat);
+        return launch_status();
+    }
     hipLaunchKernelGGL(ins_softmax_kernel, dim3(n), dim3(1024), 0, as_stream(stream), merge, ins, idx, nobj, (long)L, alpha, rowstat, nsrc);
     return launch_status();
 }

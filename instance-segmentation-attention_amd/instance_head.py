@@ -29,6 +29,7 @@ CE_WEIGHT = 10.0                            # config.py:17
 LAMBDA_L, LAMBDA_R = 0.5, 2.0               # config.py:45-46
 MAX_ITER = 2                                # config.py:56
 DROP_RATE = 0.5                             # config.py:64
+ROW_PART = 64 * 4                           # floats of chunk partials per softmax row (ISA_ROW_CHUNKS * 4, isa_kernels.h)
 
 
 class InstanceHead:
@@ -83,7 +84,8 @@ class InstanceHead:
         beta, rowstat = E.f32(n * Lp), E.f32(n * 4)
         L.check(E.lib.isa_sp_softmax(L.ptr(dot), L.ptr(sem), L.ptr(chansum), P.ptr(pre + ".l_h.weight"),
                                      P.ptr(pre + ".spatial_fc.1.weight"), P.ptr(pre + ".spatial_fc.1.bias"),
-                                     n, c, Lp, L.ptr(beta), L.ptr(rowstat), E.st()), "isa_sp_softmax")
+                                     n, c, Lp, L.ptr(beta), L.ptr(rowstat), L.ptr(E.f32(n * ROW_PART)), E.st()),
+                "isa_sp_softmax")
         scale, shift, mean, invstd = (E.f32(c) for _ in range(4))
         stats = E.scratch(2 * c * 8)
         if E.bn_train:
@@ -368,7 +370,7 @@ class InstanceHead:
             idx = idx_dev[it]
             alpha, rowstat = E.f32(n * Lp), E.f32(2 * n)
             L.check(E.lib.isa_ins_softmax(L.ptr(merge), L.ptr(ins), L.ptr(idx), n, nobj, Lp, L.ptr(alpha),
-                                          L.ptr(rowstat), n, E.st()), "isa_ins_softmax")
+                                          L.ptr(rowstat), n, L.ptr(E.f32(n * ROW_PART)), E.st()), "isa_ins_softmax")
             if injected_s_t is not None:
                 s_t = injected_s_t[it]
             else:
@@ -487,7 +489,7 @@ class InstanceHead:
         idx_flat = idx_dev.reshape(-1).contiguous()          # [G*n]
         alpha, rowstat = E.f32(R * Lp), E.f32(2 * R)
         L.check(E.lib.isa_ins_softmax(L.ptr(merge), L.ptr(ins), L.ptr(idx_flat), R, nobj, Lp, L.ptr(alpha), L.ptr(rowstat), n,
-                                      E.st()), "isa_ins_softmax")
+                                      L.ptr(E.f32(R * ROW_PART)), E.st()), "isa_ins_softmax")
         s_t = E.arena.alloc((R,), torch.int32)
         if injected_s_t is not None:
             for it in range(G):

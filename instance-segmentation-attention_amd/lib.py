@@ -102,13 +102,13 @@ SIGNATURES = {
     "isa_se_fc": [VP, VP, VP, VP, VP, I32, I32, I32, VP, VP, VP],
     "isa_chan_argmax": [P_T, P_T, VP],
     "isa_mask_dot": [P_T, VP, VP, VP, VP, VP, VP],
-    "isa_sp_softmax": [VP, VP, VP, VP, VP, VP, I32, I32, I64, VP, VP, VP],
+    "isa_sp_softmax": [VP, VP, VP, VP, VP, VP, I32, I32, I64, VP, VP, VP, VP],
     "isa_scaled_stats": [P_T, VP, VP, VP],
     "isa_sp_apply": [P_T, VP, VP, VP, VP, P_T, VP],
     "isa_maskbn_stats": [P_T, VP, VP, VP, VP],
     "isa_maskbn_finalize": [VP, VP, I32, I32, VP, VP, VP, F, I32, VP],
     "isa_maskbn_apply_pool": [P_T, VP, VP, VP, VP, F, VP, VP],
-    "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, I32, VP],
+    "isa_ins_softmax": [VP, VP, VP, I32, I32, I64, VP, VP, I32, VP, VP],
     "isa_row_argmax": [VP, VP, I32, I64, VP, VP],
     "isa_onehot_map": [VP, I32, I64, VP, VP],
     "isa_dropout_mask": [VP, I64, F, VP, VP],
