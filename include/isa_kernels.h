@@ -377,7 +377,7 @@ int isa_maskbn_bwd(const isa_tensor* e, const float* sem, const float* dmerge, c
 int isa_sp_bwd(const isa_tensor* dout, const isa_tensor* x, const float* beta, const float* m, const float* dot,
                const float* rowstat, const float* chansum, const float* scale, const float* mean,
                const float* invstd, const float* wv, const float* lh, const float* fcw, float count, int32_t train,
-               float* scratch /*zeroed: 3C + rup(n,4) + 2*n*L floats*/, const isa_tensor* dx, int32_t accumulate,
+               float* scratch /*zeroed: 3C + 2*rup(n,4) + 2*n*L floats*/, const isa_tensor* dx, int32_t accumulate,
                float* d_gamma, float* d_beta, float* d_wv, float* d_bv, float* d_lh, float* d_fcw, float* d_fcb,
                void* stream);
 int isa_gate_bwd(const isa_tensor* dout, const isa_tensor* up, const float* gmap, const isa_tensor* dup,

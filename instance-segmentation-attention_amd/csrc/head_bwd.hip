@@ -236,7 +236,7 @@ struct SpBwd {
     View dout, x, dx;
     const float *beta, *m, *scale, *mean, *invstd, *red, *ddot, *dht, *lh, *wv;
     float inv_count, inv_L; int train, accumulate;
-    float* out_red; float* dbeta_map; float* gw;
+    float* out_red; float* dbeta_map; float* gw; float* sdot;
 };
 // pass 1: red[c] += sum dq, red[C+c] += sum dq*vhat       (dq = dout*m)
 template <typename T>
@@ -326,21 +326,33 @@ __global__ __launch_bounds__(256) void sp_bwd_dbeta_kernel(SpBwd p) {
     }
     __syncthreads();
     const long pixels = (long)p.x.n * p.x.h * p.x.w;
-    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < pixels; pix += (long)gridDim.x * 256) {
-        const float bb = p.beta[pix], mm = p.m[pix];
-        float acc = 0.f;
-        for (int g = 0; g < cg; ++g) {
-            const int c0 = g * 8, nv = min(8, C - c0);
-            float d[8], xv[8];
-            load8g<T>(reinterpret_cast<const T*>(p.dout.data) + pix * p.dout.ld + c0, d, nv);
-            load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, xv, nv);
+    const unsigned hw = (unsigned)p.x.h * (unsigned)p.x.w;
+    for (long base = (long)blockIdx.x * 256; base < pixels; base += (long)gridDim.x * 256) {      // wave-uniform trip count
+        const long pix = base + threadIdx.x;
+        float t = 0.f; int row = 0;
+        if (pix < pixels) {
+            const float bb = p.beta[pix], mm = p.m[pix];
+            float acc = 0.f;
+            for (int g = 0; g < cg; ++g) {
+                const int c0 = g * 8, nv = min(8, C - c0);
+                float d[8], xv[8];
+                load8g<T>(reinterpret_cast<const T*>(p.dout.data) + pix * p.dout.ld + c0, d, nv);
+                load8g<T>(reinterpret_cast<const T*>(p.x.data) + pix * p.x.ld + c0, xv, nv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = c0 + j;
-                if (c < C) acc += sp_dv(cst[c], cst[C + c], cst[2 * C + c], cst[3 * C + c], cst[4 * C + c], p.train, d[j] * mm, xv[j], bb) * xv[j];
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + j;
+                    if (c < C) acc += sp_dv(cst[c], cst[C + c], cst[2 * C + c], cst[3 * C + c], cst[4 * C + c], p.train, d[j] * mm, xv[j], bb) * xv[j];
+                }
             }
+            p.dbeta_map[pix] = acc;
+            t = bb * acc; row = (int)((unsigned)pix / hw);             // n * h * w < 2^32 (checked on the host)
         }
-        p.dbeta_map[pix] = acc;
+        // sdot[b] = sum_p beta * dbeta of the row: what pass 3 needs before it can touch a pixel
+        const int row0 = __shfl(row, 0, 64);
+        if (__all(row == row0 || pix >= pixels)) {
+            t = wave_sum(t);
+            if ((threadIdx.x & 63) == 0 && t != 0.f) atomicAdd(p.sdot + row0, t);
+        } else if (t != 0.f) atomicAdd(p.sdot + row, t);
     }
 }
 // pass 3 (one workgroup per image): softmax + tanh backward on the maps.
@@ -369,6 +381,33 @@ __global__ __launch_bounds__(1024) void sp_bwd_row_kernel(const float* beta, con
     }
     a_w = block_sum(a_w, sh); a_b = block_sum(a_b, sh); a_h = block_sum(a_h, sh);
     if (threadIdx.x == 0) { atomicAdd(dfcw, a_w); atomicAdd(dfcb, a_b); dht[b] = a_h; }
+}
+// pass 3 with many workgroups per row: the row's sum of beta * dbeta comes from pass 2 (sdot), so every chunk of 4096 pixels is
+// independent; the three row sums leave as one atomic per workgroup (dht is part of the zeroed scratch).  The one-workgroup
+// kernel above kept n = 16 CUs busy for 76 us.
+constexpr int SPB_CHUNK = 4096;
+__global__ __launch_bounds__(256) void sp_bwd_rowc_kernel(const float* beta, const float* dbeta, const float* dot, const float* m,
+                                                          const float* rowstat, const float* fcw, const float* sdot, long L,
+                                                          float* ddot, float* dht, float* dfcw, float* dfcb) {
+    __shared__ float sh[4];
+    const int b = blockIdx.y;
+    const float cnt = rowstat[4 * b + 2], ht = rowstat[4 * b + 3], fw = fcw[0];
+    const float S = cnt > 0.f ? sdot[b] / cnt : 0.f;
+    const long o = (long)b * L, p0 = (long)blockIdx.x * SPB_CHUNK, p1 = min(L, p0 + SPB_CHUNK);
+    float a_w = 0.f, a_b = 0.f, a_h = 0.f;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        float du = 0.f;
+        if (m[o + p] >= 0.5f) {
+            const float dz = beta[o + p] * (dbeta[o + p] - S);
+            const float t = tanhf(dot[o + p] + ht);
+            a_w += dz * t; a_b += dz;
+            du = dz * fw * (1.f - t * t);
+            a_h += du;
+        }
+        ddot[o + p] = du;
+    }
+    a_w = block_sum(a_w, sh); a_b = block_sum(a_b, sh); a_h = block_sum(a_h, sh);
+    if (threadIdx.x == 0) { atomicAdd(dfcw, a_w); atomicAdd(dfcb, a_b); atomicAdd(dht + b, a_h); }
 }
 // pass 4: dx (+)= dout + dv*beta + ddot*m*wv + (dht[b]*lh/L)*m ;  gw[c] += sum_p ddot*m*x
 template <typename T>
@@ -731,18 +770,20 @@ extern "C" int isa_maskbn_bwd(const isa_tensor* e, const float* sem, const float
 extern "C" int isa_sp_bwd(const isa_tensor* dout, const isa_tensor* x, const float* beta, const float* m, const float* dot,
                           const float* rowstat, const float* chansum, const float* scale, const float* mean,
                           const float* invstd, const float* wv, const float* lh, const float* fcw, float count, int32_t train,
-                          float* scratch /* zeroed: [2C red | C gw | n dht | n*L dbeta | n*L ddot] */,
+                          float* scratch /* zeroed: [2C red | C gw | n dht | n sdot | n*L dbeta | n*L ddot], n rounded up to 4 */,
                           const isa_tensor* dx, int32_t accumulate,
                           float* d_gamma, float* d_beta, float* d_wv, float* d_bv, float* d_lh, float* d_fcw, float* d_fcb,
                           void* stream) {
     if (!tensor_ok(dout, 8) || !tensor_ok(x, 8) || !tensor_ok(dx, 8) || dout->c != x->c || dx->c != x->c || !scratch) return ISA_EINVAL;
     const int C = x->c, n = x->n; const long L = (long)x->h * x->w;
-    float* red = scratch; float* gw = red + 2 * C; float* dht = gw + C; float* dbeta = dht + ((n + 3) / 4) * 4; float* ddot = dbeta + n * L;
+    if ((long)n * L >= (1L << 32)) return ISA_EINVAL;
+    const int n4 = ((n + 3) / 4) * 4;
+    float* red = scratch; float* gw = red + 2 * C; float* dht = gw + C; float* sdot = dht + n4; float* dbeta = sdot + n4; float* ddot = dbeta + n * L;
     SpBwd p{};
     p.dout = mkview(dout); p.x = mkview(x); p.dx = mkview(dx);
     p.beta = beta; p.m = m; p.scale = scale; p.mean = mean; p.invstd = invstd; p.red = red; p.ddot = ddot; p.dht = dht;
     p.lh = lh; p.wv = wv; p.inv_count = 1.f / count; p.inv_L = 1.f / (float)L; p.train = train; p.accumulate = accumulate;
-    p.out_red = red; p.dbeta_map = dbeta; p.gw = gw;
+    p.out_red = red; p.dbeta_map = dbeta; p.gw = gw; p.sdot = sdot;
     hipStream_t s = as_stream(stream);
     const long items = (long)n * L * ((C + 7) / 8);
     const int grid = grid_keep_cg(grid_cap(cdiv(items, 256)), (C + 7) / 8);
@@ -753,7 +794,8 @@ extern "C" int isa_sp_bwd(const isa_tensor* dout, const isa_tensor* x, const flo
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(sp_bwd_dbeta_kernel<bf16_t>, dim3(grid_cap(cdiv((long)n * L, 256))), dim3(256), 5 * C * 4, s, p),
         hipLaunchKernelGGL(sp_bwd_dbeta_kernel<float>, dim3(grid_cap(cdiv((long)n * L, 256))), dim3(256), 5 * C * 4, s, p));
-    hipLaunchKernelGGL(sp_bwd_row_kernel, dim3(n), dim3(1024), 0, s, beta, dbeta, dot, m, rowstat, fcw, L, ddot, dht, d_fcw, d_fcb);
+    hipLaunchKernelGGL(sp_bwd_rowc_kernel, dim3((unsigned)((L + SPB_CHUNK - 1) / SPB_CHUNK), n), dim3(256), 0, s, beta, dbeta, dot, m,
+                       rowstat, fcw, sdot, L, ddot, dht, d_fcw, d_fcb);
     DISPATCH_T(x->dtype,
         hipLaunchKernelGGL(sp_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), C * 4, s, p),
         hipLaunchKernelGGL(sp_bwd_dx_kernel<float>, dim3(grid), dim3(256), C * 4, s, p));

@@ -102,7 +102,7 @@ class InstanceHead:
             train = 1 if E.bn_train else 0
 
             def bwd():
-                scr = E.scratch(3 * c + (n + 3) // 4 * 4 + 2 * n * Lp)
+                scr = E.scratch(3 * c + 2 * ((n + 3) // 4 * 4) + 2 * n * Lp)
                 acc = E.grads.claim(x, E)
                 L.check(E.lib.isa_sp_bwd(E.grads.grad_of(out).d(), x.d(), L.ptr(beta), L.ptr(sem), L.ptr(dot),
                                          L.ptr(rowstat), L.ptr(chansum), L.ptr(scale), L.ptr(mean), L.ptr(invstd),
