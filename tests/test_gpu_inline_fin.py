@@ -170,3 +170,39 @@ def test_two_consumers_share_one_running_update(streams, monkeypatch):
             assert rel(u, v) < 1e-5          # isa_chan_mean adds workgroup partial sums with float atomics: order varies
         else:
             assert torch.equal(u, v)
+
+
+def test_entry_points_without_the_kernel_form_launch_the_finalize_themselves(monkeypatch):
+    """isa_pro.fin handed to isa_chan_mean / isa_conv_wgrad (no in-kernel form): the entry point runs isa_bn_finalize on the
+    stream first, so the result equals the launch-per-BatchNorm path and the arrays / running statistics are written."""
+    L, Act, Engine, ParamStore, Pro = _gpu()
+    dtype = torch.bfloat16
+    c, cout, B, h, w = 32, 16, 2, 8, 8
+    x = rand(B, c, h, w, seed=3, scale=2.0) + 0.5
+    dy = rand(B, cout, h, w, seed=4)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ISA_INLINE_FIN", mode)
+        outs = []
+        for which in ("chan_mean", "wgrad"):
+            eng = make_engine(Engine, ParamStore, _bn_schema(c), _bn_tensors(c), dtype)
+            xa = to_act(Act, x, dtype)
+            lazy = eng.bn(xa, _stats(x.to(dtype).float(), 1), "bn", L.ACT_RELU6)
+            if which == "chan_mean":
+                out = torch.zeros(B, c, dtype=torch.float32, device="cuda")
+                L.check(eng.lib.isa_chan_mean(lazy.d(), lazy.p_fin(), L.ptr(out), eng.st()), "isa_chan_mean")
+            else:
+                out = torch.zeros(cout, c, dtype=torch.float32, device="cuda")
+                ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+                L.check(eng.lib.isa_conv_wgrad(lazy.d(), lazy.p_fin(), to_act(Act, dy, dtype).d(), L.ptr(out), None, L.IN_1X1,
+                                               L.OUT_PLAIN, None, 0, L.ptr(ws), ws.numel(), None, eng.st()), "isa_conv_wgrad")
+            torch.cuda.synchronize()
+            outs += [out.cpu(), lazy.bn["scale"].clone().cpu(), lazy.bn["invstd"].clone().cpu(),
+                     eng.params.view("bn.running_var").clone().cpu()]
+        res[mode] = outs
+    for i, (u, v) in enumerate(zip(res["1"], res["0"])):
+        if i == 0:
+            assert rel(u, v) < 1e-5              # isa_chan_mean: float atomics
+        else:
+            assert torch.equal(u, v), i
+    assert not torch.equal(res["1"][3], _bn_tensors(c)["bn.running_var"])
